@@ -1,0 +1,316 @@
+"""ORACLE (test infrastructure, not product code): numpy restatement of the Schur-complement LM
+solver that the HIP kernels implement.
+
+The reference has NO counterpart of this algorithm (it calls scipy TRF/LSMR with finite
+differences, src/bundle_adjustment.py:201-219; the Schur trick is only described in
+notes/schur_complement_trick.md:85-177).  This file exists so that every intermediate the GPU
+produces (residuals, 2x6 / 2x3 Jacobian blocks, U, V, W, gradients, S, rhs, step, trial cost) has a
+CPU value to be compared with, and as the tight-tolerance "polished minimum" oracle for scenes too
+large for scipy's dense exact trust region.  The maths is SURVEY.md Appendix A, in the reference's
+conventions (Xc = R(q)^T (P - t), r = observed - projected, cost = 0.5 * sum r^2).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+
+# ----------------------------------------------------------------------------- geometry
+def quat_to_rot(q: np.ndarray) -> np.ndarray:
+    q = q / np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.empty((len(q), 3, 3))
+    R[:, 0, 0] = 1 - 2 * y * y - 2 * z * z
+    R[:, 0, 1] = 2 * x * y - 2 * w * z
+    R[:, 0, 2] = 2 * x * z + 2 * w * y
+    R[:, 1, 0] = 2 * x * y + 2 * w * z
+    R[:, 1, 1] = 1 - 2 * x * x - 2 * z * z
+    R[:, 1, 2] = 2 * y * z - 2 * w * x
+    R[:, 2, 0] = 2 * x * z - 2 * w * y
+    R[:, 2, 1] = 2 * y * z + 2 * w * x
+    R[:, 2, 2] = 1 - 2 * x * x - 2 * y * y
+    return R
+
+
+def quat_mul(a, b):
+    a0, a1, a2, a3 = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    b0, b1, b2, b3 = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    return np.stack([a0 * b0 - a1 * b1 - a2 * b2 - a3 * b3, a0 * b1 + a1 * b0 + a2 * b3 - a3 * b2,
+                     a0 * b2 - a1 * b3 + a2 * b0 + a3 * b1, a0 * b3 + a1 * b2 - a2 * b1 + a3 * b0], axis=-1)
+
+
+def retract(poses: np.ndarray, dc: np.ndarray, free: np.ndarray) -> np.ndarray:
+    """t <- t + dt ; q <- normalise(q (x) [1, dtheta/2])  (SURVEY.md Appendix A)."""
+    out = poses.copy()
+    out[:, :3] += dc[:, :3] * free[:, None]
+    dq = np.concatenate([np.ones((len(poses), 1)), 0.5 * dc[:, 3:6] * free[:, None]], axis=1)
+    q = quat_mul(poses[:, 3:7], dq)
+    out[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    return out
+
+
+# ----------------------------------------------------------------------------- linearisation
+def linearize(poses, points, obs_cam, obs_pt, obs_uv, intr, want_jac=True):
+    """r (n,2), Jc = d r/d[dt, dtheta] (n,2,6), Jp = d r/dP (n,2,3).  k1=k2=k3=0 only."""
+    fx, fy, cx, cy = intr[:4]
+    R = quat_to_rot(poses[:, 3:7])[obs_cam]
+    d = points[obs_pt] - poses[obs_cam, :3]
+    xc = np.einsum("nji,nj->ni", R, d)  # R^T d
+    x, y, z = xc[:, 0], xc[:, 1], xc[:, 2]
+    iz = 1.0 / z
+    r = np.stack([obs_uv[:, 0] - (fx * x * iz + cx), obs_uv[:, 1] - (fy * y * iz + cy)], axis=1)
+    if not want_jac:
+        return r, int(np.sum(z <= 0)), None
+    n = len(x)
+    Jpi = np.zeros((n, 2, 3))
+    Jpi[:, 0, 0] = fx * iz
+    Jpi[:, 0, 2] = -fx * x * iz * iz
+    Jpi[:, 1, 1] = fy * iz
+    Jpi[:, 1, 2] = -fy * y * iz * iz
+    RT = np.transpose(R, (0, 2, 1))
+    A = np.einsum("nij,njk->nik", Jpi, RT)  # Jpi R^T
+    skew = np.zeros((n, 3, 3))
+    skew[:, 0, 1] = -z; skew[:, 0, 2] = y
+    skew[:, 1, 0] = z; skew[:, 1, 2] = -x
+    skew[:, 2, 0] = -y; skew[:, 2, 1] = x
+    Jc = np.concatenate([A, -np.einsum("nij,njk->nik", Jpi, skew)], axis=2)
+    return r, Jc, -A
+
+
+def normal_blocks(r, Jc, Jp, obs_cam, obs_pt, C, L):
+    """U (C,6,6), V (L,3,3), W (n,6,3), gc (C,6), gp (L,3), cost = 0.5 sum r^2."""
+    U = np.zeros((C, 6, 6)); V = np.zeros((L, 3, 3)); gc = np.zeros((C, 6)); gp = np.zeros((L, 3))
+    np.add.at(U, obs_cam, np.einsum("nki,nkj->nij", Jc, Jc))
+    np.add.at(V, obs_pt, np.einsum("nki,nkj->nij", Jp, Jp))
+    np.add.at(gc, obs_cam, np.einsum("nki,nk->ni", Jc, r))
+    np.add.at(gp, obs_pt, np.einsum("nki,nk->ni", Jp, r))
+    W = np.einsum("nki,nkj->nij", Jc, Jp)
+    return U, V, W, gc, gp, 0.5 * float(np.sum(r * r))
+
+
+def damped_v_inverse(V, lam, min_diag=1e-12):
+    Vd = V.copy()
+    idx = np.arange(3)
+    Vd[:, idx, idx] += lam * np.maximum(V[:, idx, idx], min_diag)
+    return np.linalg.inv(Vd)
+
+
+def schur_system(U, V, W, gc, gp, obs_cam, obs_pt, lam, free, min_diag=1e-12):
+    """Dense reduced camera system over ALL C cameras (fixed ones get identity rows):
+    S = (U + lam D_U) - sum_tracks W Vd^-1 W^T,  rhs = gc - sum W Vd^-1 gp   (solve S dc = -rhs)."""
+    C = len(U)
+    Vi = damped_v_inverse(V, lam, min_diag)
+    Y = np.einsum("nij,njk->nik", W, Vi[obs_pt])  # (n,6,3)
+    S = np.zeros((C, C, 6, 6))
+    idx = np.arange(6)
+    for c in range(C):
+        S[c, c] = U[c]
+        S[c, c, idx, idx] += lam * np.maximum(U[c, idx, idx], min_diag)
+    rhs = gc - _scatter(np.einsum("nij,nj->ni", Y, gp[obs_pt]), obs_cam, C)
+    order = np.argsort(obs_pt, kind="stable")
+    starts = np.flatnonzero(np.r_[True, np.diff(obs_pt[order]) != 0, True])
+    for s, e in zip(starts[:-1], starts[1:]):
+        k = order[s:e]
+        blk = np.einsum("aij,bkj->abik", Y[k], W[k])  # Y_a W_b^T
+        ca = obs_cam[k]
+        S[ca[:, None], ca[None, :]] -= blk
+    S = S.transpose(0, 2, 1, 3).reshape(6 * C, 6 * C)
+    fmask = np.repeat(free, 6)
+    S[~fmask, :] = 0; S[:, ~fmask] = 0
+    S[~fmask, ~fmask] = 1.0
+    rhs = rhs * free[:, None]
+    return S, rhs.reshape(-1), Vi
+
+
+def _scatter(vals, index, n):
+    out = np.zeros((n,) + vals.shape[1:])
+    np.add.at(out, index, vals)
+    return out
+
+
+def schur_system_sparse(U, V, W, gc, gp, obs_cam, obs_pt, lam, free, min_diag=1e-12):
+    """Same as schur_system but assembled as a scipy CSR matrix via vectorised pair expansion;
+    requires every track to have the same length (ring / all-visible scenes)."""
+    C = len(U)
+    Vi = damped_v_inverse(V, lam, min_diag)
+    Y = np.einsum("nij,njk->nik", W, Vi[obs_pt])
+    rhs = (gc - _scatter(np.einsum("nij,nj->ni", Y, gp[obs_pt]), obs_cam, C)) * free[:, None]
+    order = np.argsort(obs_pt, kind="stable")
+    L = len(V)
+    d = len(order) // L
+    assert d * L == len(order) and np.all(np.bincount(obs_pt, minlength=L) == d)
+    k = order.reshape(L, d)
+    a = np.repeat(k, d, axis=1).reshape(-1)
+    b = np.tile(k, (1, d)).reshape(-1)
+    blk = -np.einsum("nij,nkj->nik", Y[a], W[b])  # (L d^2, 6, 6)
+    ca, cb = obs_cam[a], obs_cam[b]
+    Ud = U.copy()
+    idx = np.arange(6)
+    Ud[:, idx, idx] += lam * np.maximum(U[:, idx, idx], min_diag)
+    blocks = np.concatenate([blk, Ud])
+    ra = np.concatenate([ca, np.arange(C)])
+    rb = np.concatenate([cb, np.arange(C)])
+    keep = free[ra] & free[rb]
+    blocks, ra, rb = blocks[keep], ra[keep], rb[keep]
+    rows = (6 * ra[:, None, None] + idx[None, :, None]) + 0 * idx[None, None, :]
+    cols = (6 * rb[:, None, None] + idx[None, None, :]) + 0 * idx[None, :, None]
+    S = sp.coo_matrix((blocks.reshape(-1), (rows.reshape(-1), cols.reshape(-1))), shape=(6 * C, 6 * C)).tocsr()
+    fixed = np.flatnonzero(~np.repeat(free, 6))
+    S = S + sp.coo_matrix((np.ones(len(fixed)), (fixed, fixed)), shape=S.shape).tocsr()
+    return S, rhs.reshape(-1), Vi
+
+
+def back_substitute(dc, Vi, W, gp, obs_cam, obs_pt, L):
+    """dp_j = -Vd_j^-1 (gp_j + sum_k W_k^T dc_{cam k})."""
+    t = gp + _scatter(np.einsum("nij,ni->nj", W, dc[obs_cam]), obs_pt, L)
+    return -np.einsum("lij,lj->li", Vi, t)
+
+
+def block_jacobi_pcg(S, b, tol, max_iter, C):
+    """Preconditioned CG on S x = b with 6x6 block-Jacobi; stops on sqrt(r^T z) <= tol * sqrt(r0^T z0)."""
+    Sd = S.toarray() if sp.issparse(S) and S.shape[0] <= 6000 else None
+    if sp.issparse(S):
+        diag_blocks = np.stack([S[6 * c:6 * c + 6, 6 * c:6 * c + 6].toarray() for c in range(C)])
+    else:
+        diag_blocks = np.stack([S[6 * c:6 * c + 6, 6 * c:6 * c + 6] for c in range(C)])
+    del Sd
+    Minv = np.linalg.inv(diag_blocks)
+    x = np.zeros_like(b)
+    r = b.copy()
+    z = np.einsum("cij,cj->ci", Minv, r.reshape(C, 6)).reshape(-1)
+    p = z.copy()
+    rz = r @ z
+    rz0 = rz
+    it = 0
+    while it < max_iter and rz > tol * tol * rz0 and rz > 0:
+        q = S @ p
+        alpha = rz / (p @ q)
+        x += alpha * p
+        r -= alpha * q
+        z = np.einsum("cij,cj->ci", Minv, r.reshape(C, 6)).reshape(-1)
+        rz_new = r @ z
+        p = z + (rz_new / rz) * p
+        rz = rz_new
+        it += 1
+    return x, it, r
+
+
+# ----------------------------------------------------------------------------- LM driver
+@dataclass
+class LMOptions:
+    max_iters: int = 100
+    ftol: float = 1e-10
+    xtol: float = 1e-12
+    gtol: float = 1e-10
+    lambda0: float = 1e-4
+    lambda_min: float = 1e-12
+    lambda_max: float = 1e12
+    min_diag: float = 1e-12
+    accept_ratio: float = 1e-4
+    guard_cheirality: bool = True  # reject a step that puts more observations behind their camera
+    linear_solver: str = "direct"  # "direct" | "pcg"
+    pcg_tol: float = 1e-2
+    pcg_max_iter: int = 500
+
+
+@dataclass
+class LMReport:
+    cost0: float = 0.0
+    cost: float = 0.0
+    iterations: int = 0  # linearisations
+    accepted: int = 0
+    status: int = 0  # 1 gtol, 2 ftol, 3 xtol, 0 max_iters
+    costs: List[float] = field(default_factory=list)
+    lambdas: List[float] = field(default_factory=list)
+    pcg_iters: List[int] = field(default_factory=list)
+    grad_inf: float = 0.0
+
+
+def lm_solve(poses, points, obs_cam, obs_pt, obs_uv, intr, free: Optional[np.ndarray] = None,
+             opt: Optional[LMOptions] = None, uniform_tracks: bool = False):
+    """Levenberg-Marquardt with Marquardt diagonal scaling, Schur elimination of the points,
+    Nielsen's lambda update.  Mirrors the control flow of csrc/ba_solver.hip::ba_solve."""
+    opt = opt or LMOptions()
+    C, L = len(poses), len(points)
+    if free is None:
+        free = np.ones(C, dtype=bool)
+        free[0] = False
+    poses = poses.copy()
+    points = points.copy()
+    rep = LMReport()
+    lam, nu = opt.lambda0, 2.0
+    r, Jc, Jp = linearize(poses, points, obs_cam, obs_pt, obs_uv, intr)
+    Jc = Jc * free[obs_cam][:, None, None]
+    U, V, W, gc, gp, cost = normal_blocks(r, Jc, Jp, obs_cam, obs_pt, C, L)
+    rep.cost0 = cost
+    rep.costs.append(cost)
+    _, nbehind, _ = linearize(poses, points, obs_cam, obs_pt, obs_uv, intr, want_jac=False)
+    it = 0
+    while it < opt.max_iters:
+        it += 1
+        ginf = max(np.abs(gc).max(), np.abs(gp).max())
+        rep.grad_inf = ginf
+        if ginf <= opt.gtol:
+            rep.status = 1
+            break
+        if uniform_tracks or C * 6 > 1500:
+            S, rhs, Vi = schur_system_sparse(U, V, W, gc, gp, obs_cam, obs_pt, lam, free, opt.min_diag)
+        else:
+            S, rhs, Vi = schur_system(U, V, W, gc, gp, obs_cam, obs_pt, lam, free, opt.min_diag)
+        if opt.linear_solver == "pcg":
+            dcv, nit, _ = block_jacobi_pcg(S, -rhs, opt.pcg_tol, opt.pcg_max_iter, C)
+            rep.pcg_iters.append(nit)
+        elif sp.issparse(S):
+            dcv = spla.spsolve(S.tocsc(), -rhs)
+        else:
+            dcv = np.linalg.solve(S, -rhs)
+        dc = dcv.reshape(C, 6) * free[:, None]
+        dp = back_substitute(dc, Vi, W, gp, obs_cam, obs_pt, L)
+        # predicted decrease of 0.5|r + J d|^2: -(g.d) - 0.5 d^T H d, from the blocks
+        gd = float(np.sum(gc * dc) + np.sum(gp * dp))
+        Wdp = np.einsum("nij,nj->ni", W, dp[obs_pt])
+        dHd = float(np.einsum("ci,cij,cj->", dc, U, dc) + np.einsum("li,lij,lj->", dp, V, dp)
+                    + 2.0 * np.sum(dc[obs_cam] * Wdp))
+        pred = -gd - 0.5 * dHd
+        poses_t = retract(poses, dc, free)
+        points_t = points + dp
+        rt, nbehind_t, _ = linearize(poses_t, points_t, obs_cam, obs_pt, obs_uv, intr, want_jac=False)
+        cost_t = 0.5 * float(np.sum(rt * rt))
+        rho = (cost - cost_t) / pred if pred > 0 else -1.0
+        if opt.guard_cheirality and nbehind_t > nbehind:
+            rho = -1.0
+        step_norm = np.sqrt(np.sum(dc * dc) + np.sum(dp * dp))
+        x_norm = np.sqrt(np.sum(poses[:, :3] ** 2) + np.sum(points ** 2) + C)
+        rep.lambdas.append(lam)
+        if np.isfinite(cost_t) and rho > opt.accept_ratio:
+            dF = cost - cost_t
+            poses, points, cost, nbehind = poses_t, points_t, cost_t, nbehind_t
+            rep.accepted += 1
+            rep.costs.append(cost)
+            lam = max(opt.lambda_min, lam * max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3))
+            nu = 2.0
+            if dF <= opt.ftol * cost:
+                rep.status = 2
+                break
+            if step_norm <= opt.xtol * (x_norm + opt.xtol):
+                rep.status = 3
+                break
+            r, Jc, Jp = linearize(poses, points, obs_cam, obs_pt, obs_uv, intr)
+            Jc = Jc * free[obs_cam][:, None, None]
+            U, V, W, gc, gp, cost = normal_blocks(r, Jc, Jp, obs_cam, obs_pt, C, L)
+        else:
+            lam = min(opt.lambda_max, lam * nu)
+            nu *= 2.0
+            if step_norm <= opt.xtol * (x_norm + opt.xtol):
+                rep.status = 3
+                break
+    rep.cost = cost
+    rep.iterations = it
+    return poses, points, rep

@@ -1,0 +1,277 @@
+"""Generate tests/golden/*.npz by running THE REFERENCE ITSELF (build container only).
+
+    python oracle/make_golden.py            # writes tests/golden/*.npz
+
+Imports /root/reference/src (pure Python; ``cv2`` is stubbed because only its drawing helpers use
+it, src/feature_observation.py:5,233,243) and records, per scene, the inputs and what the
+reference computes from them:
+
+    x0, pose0, intr, obs_cam, obs_pt, obs_uv, landmark_ids          -- inputs (packed)
+    residual_at_x0                                                   -- BundleAdjustment.residual_function
+    mask_indptr / mask_indices (small scenes)                        -- bundle_adjustment_sparsity
+    ref_x, ref_cost, ref_status, ref_nfev, ref_njev, ref_optimality  -- scipy result inside optimize()
+    polished_cost, polished_x                                        -- tight-tolerance minimum
+    kat_*                                                            -- known answers of the helper tests
+
+The scenes are built here with the reference's own classes, following the recipes of
+SURVEY.md Appendix C; the product's generator (visual-odometry_amd/scenes.py) is checked against
+these files by tests/test_scenes_golden.py.  Nothing from /root/reference is copied: fixtures hold
+only numbers.  This script never runs on the GPU box (the reference does not travel).
+"""
+
+import contextlib
+import io
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+sys.path.insert(1, ROOT)
+
+import src.bundle_adjustment as ref_ba  # noqa: E402  (the reference)
+from src.camera import PinHoleCamera  # noqa: E402
+from src.camera_pose import CameraPose, TrajectoryGenerator  # noqa: E402
+from src.feature_observation import ImageFeatures, Landmarks3D  # noqa: E402
+from src.geometry import GeometryUtils as G  # noqa: E402
+from src.landmarks import LandmarkGenerator  # noqa: E402
+
+from oracle import lm_schur_numpy as lm  # noqa: E402
+from oracle import ref_scipy_path as orc  # noqa: E402
+
+assert ref_ba.__file__.startswith("/root/reference/"), ref_ba.__file__
+
+
+# ----------------------------------------------------------------------------- scene recipes (reference classes)
+def listed_poses(spec):
+    quat_cam = G.quaternion_from_euler_angles(np.array([-np.pi / 2, 0.0, -np.pi / 2]))
+    return [CameraPose(np.array(p, dtype=float),
+                       G.quaternion_multiply(quat_cam, G.quaternion_from_euler_angles(np.array(e))), ts)
+            for p, e, ts in spec]
+
+
+TEST_POSES = [([-0.5, 0.1, 0.0], [0.02, 0.03, 0.0], 0.0), ([0.0, -0.2, 0.0], [0.04, -0.1, 0.2], 1.0),
+              ([0.0, 0.0, 0.3], [0.06, 0.02, 0.4], 2.0), ([0.0, 0.0, -0.3], [0.08, 0.3, 0.7], 3.0)]
+DEMO_POSES = TEST_POSES + [([0.0, 0.0, 0.0], [0.1, 0.05, -0.2], 0.0), ([0.0, -0.2, 0.0], [0.12, 0.0, 0.0], 1.0),
+                           ([0.0, 0.0, 0.3], [0.14, 0.0, 0.0], 2.0), ([0.0, 0.0, -0.3], [0.16, 0.0, 0.0], 3.0)]
+
+
+def render(poses, landmarks, cam, ids_per_pose=None, noise=None):
+    feats = []
+    for i, pose in enumerate(poses):
+        ids = np.arange(len(landmarks)) if ids_per_pose is None else ids_per_pose[i]
+        f = ImageFeatures.from_points_3d(pose.timestamp, 640, 480, 0, cam,
+                                         pose.transform_points_world_to_camera(landmarks[ids]), ids)
+        if noise is not None:
+            f.features_2d.points_2d = f.features_2d.points_2d + noise(len(ids))
+        feats.append(f)
+    return feats
+
+
+def to_cf0(poses, landmarks):
+    first = poses[0].copy()
+    lms = Landmarks3D(first.transform_points_world_to_camera(landmarks), np.arange(len(landmarks)))
+    return [p.convert_to_new_frame(first) for p in poses], lms
+
+
+def perturb(poses_cf0, lms_cf0, randn, lm_std, pos_std, rot_std):
+    lm_guess = Landmarks3D(lms_cf0.get_points_3d() + randn(len(lms_cf0.get_points_3d()), 3) * lm_std,
+                           lms_cf0.get_ids())
+    guesses = []
+    for pose in poses_cf0[1:]:
+        g = pose.copy()
+        g.position = g.position + randn(3) * pos_std
+        g.orientation_quaternion = G.quaternion_multiply(
+            g.orientation_quaternion, G.quaternion_from_euler_angles(randn(3) * rot_std))
+        guesses.append(g)
+    return guesses, lm_guess
+
+
+def seeded_scene(spec, n_lm, lm_std, pos_std, rot_std):
+    cam = PinHoleCamera(fx=1000.0, fy=1000.0, cx=320.0, cy=240.0)
+    landmarks = LandmarkGenerator((2.8, 3.2), (-0.5, 0.5), (-0.5, 0.5)).generate_random(num_landmarks=n_lm, seed=42)
+    poses = listed_poses(spec)
+    feats = render(poses, landmarks, cam)
+    np.random.seed(42)
+    poses_cf0, lms_cf0 = to_cf0(poses, landmarks)
+    guesses, lm_guess = perturb(poses_cf0, lms_cf0, np.random.randn, lm_std, pos_std, rot_std)
+    return cam, feats, poses_cf0, lms_cf0, guesses, lm_guess
+
+
+def noisy_scene(P, L):
+    rng = np.random.default_rng(0)
+    cam = PinHoleCamera(fx=1000.0, fy=1000.0, cx=320.0, cy=240.0)
+    landmarks = LandmarkGenerator((2.8, 3.2), (-0.5, 0.5), (-0.5, 0.5)).generate_random(num_landmarks=L, seed=0)
+    quat_cam = G.quaternion_from_euler_angles(np.array([-np.pi / 2, 0.0, -np.pi / 2]))
+    poses = []
+    for i in range(P):
+        p = rng.uniform(-0.4, 0.4, 3)
+        e = rng.uniform(-0.1, 0.1, 3)
+        poses.append(CameraPose(p, G.quaternion_multiply(quat_cam, G.quaternion_from_euler_angles(e)), float(i)))
+    feats = render(poses, landmarks, cam, noise=lambda n: rng.standard_normal((n, 2)) * 0.5)
+    poses_cf0, lms_cf0 = to_cf0(poses, landmarks)
+    guesses, lm_guess = perturb(poses_cf0, lms_cf0, lambda *s: rng.standard_normal(s if len(s) > 1 else s[0]),
+                                0.1, 0.05, 0.02)
+    return cam, feats, poses_cf0, lms_cf0, guesses, lm_guess
+
+
+def ring_scene(C, L, d):
+    rng = np.random.default_rng(0)
+    cam = PinHoleCamera(fx=500.0, fy=500.0, cx=320.0, cy=240.0)
+    poses = TrajectoryGenerator(0.1).generate_circular_trajectory(
+        center=np.array([0.0, 0.0]), radius=6.0, height=1.0, num_poses=C,
+        angular_velocity=2 * np.pi / (C * 0.1), look_at_center=True,
+        orientation_offset=CameraPose.create_look_straight_pose().quaternion)
+    r = 1.5 * np.sqrt(rng.uniform(0, 1, L))
+    th = rng.uniform(0, 2 * np.pi, L)
+    z = rng.uniform(0, 2, L)
+    landmarks = np.stack([r * np.cos(th), r * np.sin(th), z], axis=1)
+    j = np.arange(L)
+    ids_per_pose = [np.sort(np.concatenate([j[(j + k) % C == c] for k in range(d)])) for c in range(C)]
+    feats = render(poses, landmarks, cam, ids_per_pose, noise=lambda n: rng.standard_normal((n, 2)) * 0.5)
+    poses_cf0, lms_cf0 = to_cf0(poses, landmarks)
+    guesses, lm_guess = perturb(poses_cf0, lms_cf0, lambda *s: rng.standard_normal(s if len(s) > 1 else s[0]),
+                                0.05, 0.05, 0.01)
+    return cam, feats, poses_cf0, lms_cf0, guesses, lm_guess
+
+
+# ----------------------------------------------------------------------------- packing + running the reference
+def pack(cam, feats, poses_cf0, lms_cf0, guesses, lm_guess):
+    ids = lm_guess.get_ids()
+    index_of = {int(v): i for i, v in enumerate(ids)}
+    obs_cam, obs_pt, obs_uv = [], [], []
+    for i, f in enumerate(feats):
+        fid = f.get_points_2d().get_ids()
+        obs_cam.append(np.full(len(fid), i))
+        obs_pt.append(np.array([index_of[int(v)] for v in fid]))
+        obs_uv.append(f.get_points_2d().get_points_2d())
+    x0 = np.concatenate([np.concatenate([np.concatenate([g.position, g.quaternion]) for g in guesses]),
+                         lm_guess.get_points_3d().flatten()])
+    return dict(
+        intr=cam.to_vector(), pose0=np.concatenate([poses_cf0[0].position, poses_cf0[0].quaternion]),
+        poses_gt=np.array([np.concatenate([p.position, p.quaternion]) for p in poses_cf0]),
+        points_gt=lms_cf0.get_points_3d(), landmark_ids=ids.astype(np.int64),
+        obs_cam=np.concatenate(obs_cam).astype(np.int32), obs_pt=np.concatenate(obs_pt).astype(np.int32),
+        obs_uv=np.vstack(obs_uv), x0=x0, timestamps=np.array([p.timestamp for p in poses_cf0], dtype=float))
+
+
+def run_reference(scene, pk, shipped: bool):
+    cam, feats, poses_cf0, lms_cf0, guesses, lm_guess = scene
+    n_poses = len(guesses)
+    args = (poses_cf0[0], n_poses, lm_guess.get_ids(), feats, cam)
+    out = {"residual_at_x0": ref_ba.BundleAdjustment.residual_function(pk["x0"], *args)}
+    captured = {}
+    real_lsq = ref_ba.least_squares
+
+    def spy(*a, **kw):
+        captured["res"] = real_lsq(*a, **kw)
+        return captured["res"]
+
+    t0 = time.perf_counter()
+    if shipped:
+        ref_ba.least_squares = spy
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):  # dense mask print, bundle_adjustment.py:153
+                feats_o, lms_o, poses_o = ref_ba.BundleAdjustment().optimize(feats, poses_cf0[0], cam, guesses, lm_guess)
+        finally:
+            ref_ba.least_squares = real_lsq
+        res = captured["res"]
+        out["opt_points"] = lms_o.get_points_3d()
+        out["opt_poses"] = np.array([np.concatenate([p.position, p.quaternion]) for p in poses_o])
+        out["opt_uv"] = np.vstack([f.get_points_2d().get_points_2d() for f in feats_o])
+        with contextlib.redirect_stdout(io.StringIO()):
+            A = ref_ba.BundleAdjustment.bundle_adjustment_sparsity(n_poses, len(lm_guess.get_ids()), feats).tocsr()
+        out["mask_indptr"], out["mask_indices"] = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+    else:  # lean oracle: the reference residual + the reference's kwargs, vectorised mask
+        mask = orc.sparsity_mask(n_poses, len(lm_guess.get_ids()), pk["obs_cam"], pk["obs_pt"])
+        res = real_lsq(ref_ba.BundleAdjustment.residual_function, pk["x0"], jac_sparsity=mask, method="trf",
+                       x_scale="jac", ftol=1e-6, xtol=1e-6, gtol=1e-6, max_nfev=2000, args=args)
+    out["ref_seconds"] = np.array(time.perf_counter() - t0)
+    out.update(ref_x=res.x, ref_cost=np.array(res.cost), ref_status=np.array(res.status),
+               ref_nfev=np.array(res.nfev), ref_njev=np.array(res.njev), ref_optimality=np.array(res.optimality),
+               ref_residual=res.fun)
+    return out, res
+
+
+def polish(pk, res, dense):
+    n_poses = (len(pk["poses_gt"]) - 1)
+    a = (pk["pose0"], n_poses, pk["obs_cam"], pk["obs_pt"], pk["obs_uv"], pk["intr"])
+    if dense:
+        pol = orc.polish(res.x, *a, dense=True, max_nfev=300)
+        return dict(polished_cost=np.array(pol.cost), polished_x=pol.x, polished_by=np.array("scipy trf exact"))
+    poses = np.vstack([pk["pose0"][None], res.x[: n_poses * 7].reshape(-1, 7)])
+    poses[:, 3:7] /= np.linalg.norm(poses[:, 3:7], axis=1, keepdims=True)
+    pts = res.x[n_poses * 7:].reshape(-1, 3)
+    opt = lm.LMOptions(max_iters=200, ftol=1e-14, gtol=1e-9, xtol=1e-14)
+    P, X, rep = lm.lm_solve(poses, pts, pk["obs_cam"], pk["obs_pt"], pk["obs_uv"], pk["intr"], opt=opt,
+                            uniform_tracks=True)
+    x = np.concatenate([P[1:].reshape(-1), X.reshape(-1)])
+    return dict(polished_cost=np.array(rep.cost), polished_x=x, polished_by=np.array("oracle/lm_schur_numpy direct"))
+
+
+def known_answers():
+    """Outputs of the reference helpers on the inputs its own unit tests use
+    (tests/test_camera.py:97-109, tests/test_camera_pose.py:120-177, tests/test_geometry.py:92-146)."""
+    cam = PinHoleCamera(fx=500.0, fy=500.0, cx=320.0, cy=240.0)
+    camd = PinHoleCamera(fx=500.0, fy=400.0, cx=320.0, cy=240.0, k1=0.1, k2=-0.05, k3=0.01)
+    pts = np.array([[1.0, 2.0, 5.0], [-1.0, 0.5, 2.0], [0.0, 0.0, 1.0], [0.3, -0.7, -2.0]])
+    q = G.quaternion_from_euler_angles(np.array([0.3, -0.2, 0.5]))
+    q2 = G.quaternion_from_euler_angles(np.array([-1.0, 0.4, 2.5]))
+    pose = CameraPose(np.array([0.5, -1.0, 2.0]), q, 1.5)
+    return dict(kat_points=pts, kat_project=cam.project(pts), kat_project_dist=camd.project(pts),
+                kat_q=q, kat_q2=q2, kat_R=G.rotation_matrix_from_quaternion(q),
+                kat_qmul=G.quaternion_multiply(q, q2), kat_qinv=G.quaternion_inverse(q2 * 1.3),
+                kat_w2c=pose.transform_points_world_to_camera(pts),
+                kat_newframe=np.concatenate([CameraPose(np.array([1.0, 2.0, 3.0]), q2).convert_to_new_frame(pose).position,
+                                             CameraPose(np.array([1.0, 2.0, 3.0]), q2).convert_to_new_frame(pose).quaternion]),
+                kat_lm=LandmarkGenerator((2.8, 3.2), (-0.5, 0.5), (-0.5, 0.5)).generate_random(num_landmarks=50, seed=42)[:3],
+                kat_axis_angle=G.quaternion_from_axis_angle(np.array([0.0, 0.0, 2.0]), 0.7),
+                kat_qrot_branches=np.array([G.quaternion_from_rotation_matrix(
+                    G.rotation_matrix_from_euler_angles(np.array(e))) for e in
+                    ([3.0, 0.1, 0.2], [0.1, 3.0, 0.2], [0.1, 0.2, 3.0], [0.1, 0.2, 0.3])]))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    jobs = [
+        ("test_scene_convergence", lambda: seeded_scene(TEST_POSES, 50, 0.2, 0.1, 0.05), True, True, False),
+        ("test_scene_landmark_accuracy", lambda: seeded_scene(TEST_POSES, 50, 0.3, 0.05, 0.02), True, True, False),
+        ("demo_scene", lambda: seeded_scene(DEMO_POSES, 100, 0.5, 0.5, 0.1), True, True, False),
+        ("noisy_10x300", lambda: noisy_scene(10, 300), True, True, False),
+        ("ring_50x2000", lambda: ring_scene(50, 2000, 10), False, False, True),
+    ]
+    for name, make, shipped, dense, thin in jobs:
+        t0 = time.time()
+        scene = make()
+        pk = pack(*scene)
+        out, res = run_reference(scene, pk, shipped)
+        out.update(polish(pk, res, dense))
+        out["rms_reproj"] = np.array(orc.rms_reprojection(res.fun))
+        if thin:  # keep the file small: the product generator rebuilds the arrays, sampled values pin them
+            full = dict(pk)
+            sample = np.arange(0, len(full["obs_cam"]), 37)
+            pk = dict(intr=full["intr"], pose0=full["pose0"], ring_params=np.array([50, 2000, 10]),
+                      sample=sample, obs_cam_s=full["obs_cam"][sample], obs_pt_s=full["obs_pt"][sample],
+                      obs_uv_s=full["obs_uv"][sample], x0_s=full["x0"][::37], x0_sum=np.array(full["x0"].sum()),
+                      obs_uv_sum=np.array(full["obs_uv"].sum()), poses_gt=full["poses_gt"])
+            out["residual_at_x0_s"] = out.pop("residual_at_x0")[::37]
+            out["ref_x_s"] = out.pop("ref_x")[::37]
+            out["polished_x_s"] = out.pop("polished_x")[::37]
+            out.pop("ref_residual")
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **pk, **out)
+        print(f"{name}: ref cost {float(out['ref_cost']):.12g} status {int(out['ref_status'])} nfev "
+              f"{int(out['ref_nfev'])}  polished {float(out['polished_cost']):.12g}  ({time.time() - t0:.1f}s)")
+    np.savez_compressed(os.path.join(OUT, "known_answers.npz"), **known_answers())
+    print("known_answers written")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,101 @@
+"""The product's scene generator and value types against scenes built with the reference's own
+classes (tests/golden, oracle/make_golden.py).  CPU only."""
+
+import numpy as np
+import pytest
+
+import scenes
+from src.camera import PinHoleCamera
+from src.camera_pose import CameraPose
+from src.geometry import GeometryUtils as G
+from src.landmarks import LandmarkGenerator
+from src.validation_error import ProcessingError, ValidationError
+
+KEYS = ["x0", "pose0", "intr", "obs_cam", "obs_pt", "obs_uv", "landmark_ids", "poses_gt", "points_gt"]
+
+
+@pytest.mark.parametrize("name,make", [
+    ("test_scene_convergence", lambda: scenes.reference_test_scene()),
+    ("test_scene_landmark_accuracy", lambda: scenes.reference_test_scene(0.3, 0.05, 0.02)),
+    ("demo_scene", scenes.demo_scene),
+    ("noisy_10x300", lambda: scenes.noisy_scene(10, 300)),
+])
+def test_scene_equals_reference_built_scene(golden, name, make):
+    g, s = golden(name), make()
+    for k in KEYS:
+        if g[k].dtype.kind in "iu":
+            assert np.array_equal(g[k], s[k]), k
+        else:
+            np.testing.assert_allclose(s[k], g[k], rtol=0, atol=1e-12, err_msg=k)
+
+
+def test_ring_scene_equals_reference_built_scene(golden):
+    g = golden("ring_50x2000")
+    C, L, d = (int(v) for v in g["ring_params"])
+    s = scenes.ring_scene(C, L, d)
+    sm = g["sample"]
+    assert np.array_equal(s["obs_cam"][sm], g["obs_cam_s"])
+    assert np.array_equal(s["obs_pt"][sm], g["obs_pt_s"])
+    np.testing.assert_allclose(s["obs_uv"][sm], g["obs_uv_s"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(s["x0"][::37], g["x0_s"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(s["poses_gt"], g["poses_gt"], rtol=0, atol=1e-12)
+    assert abs(s["x0"].sum() - float(g["x0_sum"])) < 1e-8
+    assert abs(s["obs_uv"].sum() - float(g["obs_uv_sum"])) < 1e-5
+    counts = np.bincount(s["obs_cam"], minlength=C)
+    assert np.all(counts == L * d // C)
+    for c in (0, 7, C - 1):  # ids ascending inside every image
+        assert np.all(np.diff(s["obs_pt"][s["obs_cam"] == c]) > 0)
+
+
+def test_known_answers(golden):
+    k = golden("known_answers")
+    cam = PinHoleCamera(fx=500.0, fy=500.0, cx=320.0, cy=240.0)
+    camd = PinHoleCamera(fx=500.0, fy=400.0, cx=320.0, cy=240.0, k1=0.1, k2=-0.05, k3=0.01)
+    pts = k["kat_points"]
+    np.testing.assert_allclose(cam.project(pts), k["kat_project"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(camd.project(pts), k["kat_project_dist"], rtol=0, atol=1e-12)
+    q = G.quaternion_from_euler_angles(np.array([0.3, -0.2, 0.5]))
+    q2 = G.quaternion_from_euler_angles(np.array([-1.0, 0.4, 2.5]))
+    np.testing.assert_allclose(q, k["kat_q"], atol=1e-15)
+    np.testing.assert_allclose(q2, k["kat_q2"], atol=1e-15)
+    np.testing.assert_allclose(G.rotation_matrix_from_quaternion(q), k["kat_R"], atol=1e-15)
+    np.testing.assert_allclose(G.quaternion_multiply(q, q2), k["kat_qmul"], atol=1e-15)
+    np.testing.assert_allclose(G.quaternion_inverse(q2 * 1.3), k["kat_qinv"], atol=1e-15)
+    pose = CameraPose(np.array([0.5, -1.0, 2.0]), q, 1.5)
+    np.testing.assert_allclose(pose.transform_points_world_to_camera(pts), k["kat_w2c"], atol=1e-14)
+    nf = CameraPose(np.array([1.0, 2.0, 3.0]), q2).convert_to_new_frame(pose)
+    np.testing.assert_allclose(np.concatenate([nf.position, nf.quaternion]), k["kat_newframe"], atol=1e-14)
+    lmk = LandmarkGenerator((2.8, 3.2), (-0.5, 0.5), (-0.5, 0.5)).generate_random(num_landmarks=50, seed=42)
+    np.testing.assert_allclose(lmk[:3], k["kat_lm"], atol=0)
+    # anchor quoted in SURVEY.md section 4
+    np.testing.assert_allclose(lmk[0], [3.10958242, -0.3000918, 0.40858069], atol=1e-8)
+    np.testing.assert_allclose(G.quaternion_from_axis_angle(np.array([0.0, 0.0, 2.0]), 0.7), k["kat_axis_angle"], atol=1e-15)
+    got = np.array([G.quaternion_from_rotation_matrix(G.rotation_matrix_from_euler_angles(np.array(e)))
+                    for e in ([3.0, 0.1, 0.2], [0.1, 3.0, 0.2], [0.1, 0.2, 3.0], [0.1, 0.2, 0.3])])
+    np.testing.assert_allclose(got, k["kat_qrot_branches"], atol=1e-15)
+
+
+def test_reference_helper_known_answers():
+    # reference tests/test_camera.py:97-109 (projection formula) and test_camera_pose.py:156-177 style
+    cam = PinHoleCamera(fx=800.0, fy=600.0, cx=320.0, cy=240.0)
+    uv = cam.project(np.array([[1.0, 2.0, 4.0]]))
+    np.testing.assert_allclose(uv, [[800.0 * 0.25 + 320.0, 600.0 * 0.5 + 240.0]], atol=1e-10)
+    # 90 degrees about z: camera->world R maps x to y
+    q = np.array([np.cos(np.pi / 4), 0.0, 0.0, np.sin(np.pi / 4)])
+    R = G.rotation_matrix_from_quaternion(q)
+    np.testing.assert_allclose(R @ np.array([1.0, 0.0, 0.0]), [0.0, 1.0, 0.0], atol=1e-15)
+    pose = CameraPose(np.array([1.0, 0.0, 0.0]), q)
+    np.testing.assert_allclose(pose.transform_points_world_to_camera(np.array([[1.0, 1.0, 0.0]])), [[1.0, 0.0, 0.0]], atol=1e-15)
+
+
+def test_error_conventions():
+    cam = PinHoleCamera(fx=1.0, fy=1.0, cx=0.0, cy=0.0)
+    with pytest.raises(ProcessingError):
+        cam.project(np.array([[1.0, 1.0, 0.0]]))
+    with pytest.raises(ValidationError):
+        cam.project(np.array([[1.0, np.nan, 1.0]]))
+    with pytest.raises(ValidationError):
+        CameraPose(np.zeros(3), np.array([2.0, 0.0, 0.0, 0.0]))
+    with pytest.raises(ValidationError):
+        PinHoleCamera(fx=-1.0, fy=1.0, cx=0.0, cy=0.0)
+    assert issubclass(ValidationError, ValueError) and issubclass(ProcessingError, RuntimeError)
