@@ -1,0 +1,168 @@
+/*
+ * ba_amd.h -- C ABI of the MI355X-native sparse bundle-adjustment solver (libba_amd.so).
+ *
+ * This is the drop-in boundary for the hot path of AubreyC/visual-odometry's
+ * src/bundle_adjustment.py.  The reference has no FFI: the path is one Python method,
+ *     BundleAdjustment.optimize(image_features_list, camera_pose_initial, camera_model,
+ *                               camera_poses_guess, points3d_guess)        (bundle_adjustment.py:156-163)
+ * which packs a parameter vector (:178-194), builds a sparsity mask (:196 -> :90-154) and calls
+ * scipy.optimize.least_squares(residual_function, ...) (:201-219).  The entry points below are what a
+ * ctypes binding of that method calls instead (visual-odometry_amd/src/_native.py; INTEGRATION.md
+ * shows the stub a maintainer of the reference would add).
+ *
+ * Conventions (the reference's): pose = [tx,ty,tz, qw,qx,qy,qz] (position of the camera centre in
+ * the world frame, unit quaternion rotating camera->world, geometry.py:192-213); camera-frame point
+ * Xc = R(q)^T (P - t) (camera_pose.py:85-86); pixel = (fx x/z + cx, fy y/z + cy), optionally times the
+ * radial factor 1 + k1 r^2 + k2 r^4 + k3 r^6 (camera.py:134-165); residual = observed - projected
+ * (bundle_adjustment.py:80-83); cost = 0.5 * sum residual^2 (scipy convention).
+ *
+ * All pointers are HOST pointers to C-contiguous arrays owned by the caller; the library owns every
+ * device allocation behind the opaque handle.  Every call is synchronous.  A handle may be used by one
+ * thread at a time; distinct handles are independent.  Every function that returns int returns a
+ * ba_status (0 = ok); ba_last_error(handle) gives the text for the last non-zero status.
+ * fp64 throughout; indices are int32.
+ */
+#ifndef BA_AMD_H
+#define BA_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BA_AMD_VERSION 100 /* 0.1.0 */
+#define BA_HISTORY 128     /* per-iteration history entries kept in ba_report */
+
+typedef enum {
+  BA_OK = 0,
+  BA_ERR_INVALID = 1,   /* bad argument (shape, index out of range, non-finite input)  -> ValidationError */
+  BA_ERR_NUMERICAL = 2, /* non-finite cost at the initial point, z == 0               -> ProcessingError */
+  BA_ERR_DEVICE = 3,    /* HIP / RCCL runtime error                                   -> RuntimeError    */
+  BA_ERR_NOMEM = 4,     /* host or device allocation failed                           -> RuntimeError    */
+  BA_ERR_STATE = 5      /* call order (e.g. solve before set_problem)                 -> RuntimeError    */
+} ba_status;
+
+/* Termination reason, same vocabulary as scipy's OptimizeResult.status that the reference's
+ * least_squares call produces (scipy/optimize/_lsq/common.py:705-717): */
+typedef enum { BA_STOP_MAX_ITERS = 0, BA_STOP_GTOL = 1, BA_STOP_FTOL = 2, BA_STOP_XTOL = 3 } ba_stop;
+
+typedef enum { BA_SOLVER_AUTO = 0, BA_SOLVER_PCG = 1, BA_SOLVER_DENSE_CHOLESKY = 2 } ba_linear_solver;
+
+/* Solver settings.  The reference hard-codes its settings as literals in the least_squares call
+ * (bundle_adjustment.py:201-212: ftol = xtol = gtol = 1e-6, max_nfev = 2000); defaults here are
+ * tighter so that the converged cost is at or below the reference's. */
+typedef struct {
+  int32_t max_iters;        /* LM iterations (linearisations), default 200 */
+  double ftol;              /* stop when an accepted step lowers the cost by <= ftol * cost; 1e-10 */
+  double xtol;              /* stop when |step| <= xtol * (xtol + |x|); 1e-12 */
+  double gtol;              /* stop when |J^T r|_inf <= gtol; 1e-10 */
+  double lambda0;           /* initial LM damping (Marquardt-scaled), 1e-4 */
+  double lambda_min;        /* 1e-12 */
+  double lambda_max;        /* 1e12 */
+  double min_diag;          /* floor of the Marquardt diagonal, 1e-12 */
+  double accept_ratio;      /* accept a step when actual/predicted decrease > this, 1e-4 */
+  int32_t guard_cheirality; /* reject a step that moves more observations behind their camera, 1 */
+  int32_t linear_solver;    /* ba_linear_solver, default BA_SOLVER_AUTO */
+  double pcg_tol;           /* relative residual (M^-1 norm) at which block-Jacobi PCG stops, 1e-2 */
+  int32_t pcg_max_iter;     /* 1000 */
+  int32_t pcg_check_every;  /* PCG iterations between host polls of the device-side stop flag, 10 */
+  int32_t device;           /* HIP device ordinal; -1 = current device */
+  int32_t verbose;          /* 1 = print one line per LM iteration to stderr */
+} ba_options;
+
+typedef struct {
+  double cost0;        /* 0.5 sum r^2 at the initial guess */
+  double cost;         /* at the returned estimate */
+  double grad_inf;     /* |J^T r|_inf at the last linearisation */
+  double lambda;       /* final damping */
+  double rms_reproj;   /* sqrt(2 cost / nobs), pixels */
+  int32_t iterations;  /* linearise+solve rounds, accepted + rejected */
+  int32_t accepted;
+  int32_t linearizations; /* Jacobian evaluations (1 + accepted) */
+  int32_t status;      /* ba_stop */
+  int32_t pcg_iters;   /* total PCG iterations */
+  int32_t nobs;
+  double solve_ms;     /* wall time inside the solve, device-synchronised */
+  double setup_ms;     /* wall time of the last ba_set_problem (index build + upload) */
+  int32_t n_history;
+  double cost_history[BA_HISTORY];   /* cost after each iteration */
+  double lambda_history[BA_HISTORY]; /* damping used by each iteration */
+  int32_t pcg_history[BA_HISTORY];   /* PCG iterations of each iteration */
+  int32_t accepted_history[BA_HISTORY];
+} ba_report;
+
+typedef struct ba_handle ba_handle;
+
+/* Library / device queries (no reference counterpart; the reference is CPU-only). */
+int ba_version(void);
+int ba_device_count(void);
+
+/* Fill `opt` with the defaults listed above.  Replaces the literal kwargs of
+ * bundle_adjustment.py:201-212. */
+void ba_default_options(ba_options* opt);
+
+/* Create / destroy a solver bound to one GPU.  BundleAdjustment() is stateless
+ * (bundle_adjustment.py:15-16); the handle holds the device buffers of one problem at a time. */
+int ba_create(const ba_options* opt, ba_handle** out);
+void ba_destroy(ba_handle* h);
+const char* ba_last_error(const ba_handle* h);
+
+/* Define the problem structure.  Replaces the packing of bundle_adjustment.py:178-194 and the mask
+ * construction of bundle_adjustment_sparsity (:90-154): the (camera, landmark) index pairs ARE the
+ * sparsity pattern.
+ *   n_cams   C  images/poses including the fixed ones (reference: len(image_features_list))
+ *   n_pts    L  landmarks (reference: len(points3d_guess.get_ids()))
+ *   n_obs       observations, in any order; observation k is pixel (obs_uv[2k], obs_uv[2k+1]) of
+ *               landmark INDEX obs_pt[k] seen in image obs_cam[k]
+ *   intr[7]     fx, fy, cx, cy, k1, k2, k3   (PinHoleCamera.to_vector, camera.py:93-99)
+ *   fixed[C]    non-zero = pose is held constant (reference: only image 0, :51-52,141); may be NULL
+ *               for "camera 0 fixed"
+ * The library sorts observations into landmark tracks and builds the block pattern of the reduced
+ * camera system once here. */
+int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int32_t n_obs, const int32_t* obs_cam,
+                   const int32_t* obs_pt, const double* obs_uv, const double* intr, const uint8_t* fixed);
+
+/* Optimise.  poses[C*7] and points[L*3] are in/out: initial guess in, estimate out (quaternions come
+ * back unit-length; fixed poses and unobserved landmarks come back untouched).  Replaces the
+ * least_squares call of bundle_adjustment.py:201-219 plus the unpacking of :221-244.
+ * Non-convergence is not an error (the reference ignores scipy's status): read report->status. */
+int ba_solve(ba_handle* h, double* poses, double* points, ba_report* report);
+
+/* The three steps of ba_solve separately, for callers that keep data resident on the GPU between
+ * calls (bench.py times ba_solve_resident only): upload a guess; solve from the uploaded guess
+ * (repeatable: each call restarts from it); download the estimate of the last solve. */
+int ba_upload_guess(ba_handle* h, const double* poses, const double* points);
+int ba_solve_resident(ba_handle* h, ba_report* report);
+int ba_download_estimate(ba_handle* h, double* poses, double* points);
+
+/* Residual vector and cost at (poses, points), residuals[2*n_obs] in the caller's observation
+ * order ([u0, v0, u1, v1, ...]); residuals may be NULL.  Replaces
+ * BundleAdjustment.residual_function (bundle_adjustment.py:20-87).  n_behind (may be NULL) receives
+ * the number of observations with z <= 0.  Returns BA_ERR_NUMERICAL if some z == 0, as
+ * PinHoleCamera.project raises ProcessingError there (camera.py:129-132). */
+int ba_evaluate(ba_handle* h, const double* poses, const double* points, double* residuals, double* cost,
+                int32_t* n_behind);
+
+/* Analytic Jacobian blocks in the caller's observation order: Jc[n_obs*12] = d r / d(dt, dtheta)
+ * (2x6 row-major, zero for fixed poses), Jp[n_obs*6] = d r / dP (2x3).  The reference has no analytic
+ * Jacobian (scipy differentiates numerically, scipy/optimize/_numdiff.py); exported so tests can check
+ * the blocks against finite differences of the reference residual. */
+int ba_jacobian_blocks(ba_handle* h, const double* poses, const double* points, double* Jc, double* Jp);
+
+/* Debug export of one linearisation at (poses, points) with damping lambda, in the caller's index
+ * order: U[C*36], V[L*9], W[n_obs*18] (6x3 row-major), gc[C*6], gp[L*3], S[(6C)^2] dense row-major with
+ * identity rows for fixed cameras, rhs[6C] (the reduced system is S dc = -rhs), and the LM step
+ * dc[C*6], dp[L*3] from the configured linear solver.  Any pointer may be NULL.  No reference
+ * counterpart (the reference never forms normal equations). */
+int ba_debug_linearization(ba_handle* h, const double* poses, const double* points, double lambda, double* U,
+                           double* V, double* W, double* gc, double* gp, double* S, double* rhs, double* dc,
+                           double* dp);
+
+/* Number of stored 6x6 blocks of the reduced camera system (upper triangle incl. diagonal). */
+int ba_schur_block_count(const ba_handle* h, int64_t* n_upper_blocks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BA_AMD_H */

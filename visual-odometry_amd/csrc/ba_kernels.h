@@ -1,0 +1,583 @@
+// HIP kernels of the sparse bundle-adjustment solver (gfx950 / MI355X, fp64).
+//
+// Data layout in HBM (all device pointers live in DeviceProblem, ba_solver.hip fills it):
+//   observations, sorted by (internal landmark order, camera): SoA  o_cam[n] o_u[n] o_v[n]  (+ o_src[n]
+//       = caller's index, used only by the export kernels); tracks are CSR: lm_ptr[L_obs+1]
+//   poses  AoS [C][7], points AoS [L][3] (internal landmark order)
+//   W      SoA [18][n]   (6x3 coupling block of observation k = W[(3 i + j) * n + k])
+//   V      SoA [6][L]    (xx xy xz yy yz zz), gp SoA [3][L]
+//   Ugc    AoS [C][27]   (21 upper-triangle entries of U, then 6 of gc), accumulated by atomics
+//   S      6x6 blocks, row-major 36 doubles: upper blocks (incl. diagonal) in row-major (i, j>=i)
+//          order = slots [0, nu); mirrored strictly-lower blocks = slots [nu, nu + nl)
+//   vectors over free cameras: [Cf][6]
+//
+// Every kernel states the bytes it must move per unit (its HBM roofline numerator).
+#pragma once
+#include "ba_device.h"
+
+enum ScalarSlot {
+  SC_COST = 0, SC_COST_T, SC_GDOT, SC_DHD, SC_DNORM2, SC_XNORM2, SC_GINF, SC_NBEHIND, SC_NBEHIND_T, SC_BADV,
+  SC_ZEROZ, SC_NONFINITE,
+  SC_RZ = 16, SC_RZ0, SC_PQ, SC_RZNEW, SC_DONE, SC_PCGIT,
+  SC_COUNT = 32
+};
+
+struct DeviceProblem {
+  int C, Cf, L, L_obs, n;  // cameras, free cameras, landmarks, landmarks with >= 1 observation, observations
+  Intrinsics K;
+  // structure (constant per problem)
+  const int* o_cam; const double* o_u; const double* o_v; const int* o_src; const int* o_lm;
+  const int* lm_ptr;     // [L_obs + 1]
+  const int* cam2free;   // [C]   -1 = fixed
+  const int* free2cam;   // [Cf]
+  const int* urow_ptr;   // [Cf + 1] upper-triangle block rows
+  const int* ucol;       // [nu]
+  const int* urow;       // [nu]   row of each upper slot
+  const int* diag_slot;  // [Cf]
+  const int* low_of;     // [nu]   lower-mirror slot of upper slot s, or -1 on the diagonal
+  const int* brow_ptr;   // [Cf + 1] full (both triangles) block rows for SpMV
+  const int* bcol;       // [nb]
+  const int* bslot;      // [nb]
+  int nu, nl, nb;
+  // state
+  double* W; double* V; double* gp; double* Ugc;
+  double* S; double* rhs; double* Udiag; double* Minv;
+  double* dc; double* r; double* z; double* p; double* q;   // PCG vectors (dc is the solution x)
+  double* scal;
+};
+
+// ------------------------------------------------------------------------------------------------
+// k_linearize: residual + analytic 2x6 / 2x3 Jacobian per observation, block assembly.
+// One group of G lanes walks a contiguous range of landmark tracks; lane s of the group takes
+// observation slot s (+G, +2G, ...) of each track.  V and gp are reduced across the group with
+// shuffles and stored (tracks are exclusively owned: no atomics).  U/gc are accumulated in registers
+// for as long as the lane keeps seeing the same camera (tracks are camera-sorted and landmarks are
+// ordered by camera signature, so runs are long) and flushed with one fp64 atomic per entry per run.
+// Algorithmic bytes: read 20 B/obs (cam idx + u + v) + 24 B/landmark (P), write W 144 B/obs,
+// V 48 + gp 24 B/landmark, U/gc 216 B per camera run.
+template <int G>
+__global__ __launch_bounds__(256) void k_linearize(DeviceProblem d, const double* __restrict__ poses,
+                                                   const double* __restrict__ pts, int lm_per_group) {
+  __shared__ double red[4];
+  const int lane = threadIdx.x & (G - 1);
+  const long group = ((long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const long j0 = group * lm_per_group;
+  const long j1 = min((long)d.L_obs, j0 + lm_per_group);
+  const long n = d.n;
+  double acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+  int cur_cam = -1;
+  double cost = 0.0, gmax = 0.0;
+  int nbehind = 0, nzero = 0;
+  for (long j = j0; j < j1; ++j) {
+    const int kb = d.lm_ptr[j], ke = d.lm_ptr[j + 1];
+    const double P[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
+    double v[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    for (int k0 = kb; k0 < ke; k0 += G) {
+      const int k = k0 + lane;
+      if (k < ke) {
+        const int cam = d.o_cam[k];
+        double r[2], Jc[12], Jp[6], zc;
+        linearize_obs(d.K, poses + 7 * cam, P, d.o_u[k], d.o_v[k], r, Jc, Jp, zc);
+        nbehind += (zc <= 0.0);
+        nzero += (zc == 0.0);
+        cost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
+        v[0] += Jp[0] * Jp[0] + Jp[3] * Jp[3];
+        v[1] += Jp[0] * Jp[1] + Jp[3] * Jp[4];
+        v[2] += Jp[0] * Jp[2] + Jp[3] * Jp[5];
+        v[3] += Jp[1] * Jp[1] + Jp[4] * Jp[4];
+        v[4] += Jp[1] * Jp[2] + Jp[4] * Jp[5];
+        v[5] += Jp[2] * Jp[2] + Jp[5] * Jp[5];
+        g[0] += Jp[0] * r[0] + Jp[3] * r[1];
+        g[1] += Jp[1] * r[0] + Jp[4] * r[1];
+        g[2] += Jp[2] * r[0] + Jp[5] * r[1];
+        const bool is_free = d.cam2free[cam] >= 0;
+        if (!is_free) {
+#pragma unroll
+          for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) d.W[(long)(3 * i + c) * n + k] = Jc[i] * Jp[c] + Jc[6 + i] * Jp[3 + c];
+        if (is_free) {
+          if (cam != cur_cam) {
+            if (cur_cam >= 0) {
+#pragma unroll
+              for (int i = 0; i < 27; ++i) atomic_add_f64(&d.Ugc[(long)cur_cam * 27 + i], acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+            cur_cam = cam;
+          }
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int c = i; c < 6; ++c) acc[sym6_index(i, c)] += Jc[i] * Jc[c] + Jc[6 + i] * Jc[6 + c];
+            acc[21 + i] += Jc[i] * r[0] + Jc[6 + i] * r[1];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = group_sum<G>(v[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g[i] = group_sum<G>(g[i]);
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) d.V[(long)i * d.L + j] = v[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) d.gp[(long)i * d.L + j] = g[i];
+      gmax = fmax(gmax, fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2]))));
+    }
+  }
+  if (cur_cam >= 0) {
+#pragma unroll
+    for (int i = 0; i < 27; ++i) atomic_add_f64(&d.Ugc[(long)cur_cam * 27 + i], acc[i]);
+  }
+  const double bc = block_sum_256(cost, red);
+  const double bb = block_sum_256((double)nbehind, red);
+  const double bz = block_sum_256((double)nzero, red);
+  const double bg = block_max_256(gmax, red);
+  if (threadIdx.x == 0) {
+    atomic_add_f64(&d.scal[SC_COST], bc);
+    if (bb != 0.0) atomic_add_f64(&d.scal[SC_NBEHIND], bb);
+    if (bz != 0.0) atomic_add_f64(&d.scal[SC_ZEROZ], bz);
+    atomic_max_nonneg(&d.scal[SC_GINF], bg);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_cost: residuals only (trial-point evaluation, ba_evaluate).  24 B/obs (+ cached P, pose).
+// Flat over observations; the landmark of observation k is found from o_lm[k].
+__global__ __launch_bounds__(256) void k_cost(DeviceProblem d,
+                                              const double* __restrict__ poses, const double* __restrict__ pts,
+                                              int cost_slot, int behind_slot, double* __restrict__ res_out) {
+  __shared__ double red[4];
+  double cost = 0.0;
+  int nbehind = 0, nzero = 0;
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < d.n; k += (long)gridDim.x * blockDim.x) {
+    const int cam = d.o_cam[k];
+    const long j = d.o_lm[k];
+    const double P[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
+    double R[9], X[3], r0, r1;
+    quat_to_R(poses + 7 * cam + 3, R);
+    to_camera(R, poses + 7 * cam, P, X);
+    reproject(d.K, X, d.o_u[k], d.o_v[k], r0, r1);
+    nbehind += (X[2] <= 0.0);
+    nzero += (X[2] == 0.0);
+    cost += 0.5 * (r0 * r0 + r1 * r1);
+    if (res_out) {
+      const long s = d.o_src[k];
+      res_out[2 * s] = r0;
+      res_out[2 * s + 1] = r1;
+    }
+  }
+  const double bc = block_sum_256(cost, red);
+  const double bb = block_sum_256((double)nbehind, red);
+  const double bz = block_sum_256((double)nzero, red);
+  if (threadIdx.x == 0) {
+    atomic_add_f64(&d.scal[cost_slot], bc);
+    if (bb != 0.0) atomic_add_f64(&d.scal[behind_slot], bb);
+    if (bz != 0.0) atomic_add_f64(&d.scal[SC_ZEROZ], bz);
+  }
+}
+
+// Export kernel for ba_jacobian_blocks (caller's observation order).
+__global__ __launch_bounds__(256) void k_export_jac(DeviceProblem d,
+                                                    const double* __restrict__ poses, const double* __restrict__ pts,
+                                                    double* __restrict__ Jc_out, double* __restrict__ Jp_out) {
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < d.n; k += (long)gridDim.x * blockDim.x) {
+    const int cam = d.o_cam[k];
+    const long j = d.o_lm[k];
+    const double P[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
+    double r[2], Jc[12], Jp[6], zc;
+    linearize_obs(d.K, poses + 7 * cam, P, d.o_u[k], d.o_v[k], r, Jc, Jp, zc);
+    const bool is_free = d.cam2free[cam] >= 0;
+    const long s = d.o_src[k];
+    for (int i = 0; i < 12; ++i) Jc_out[12 * s + i] = is_free ? Jc[i] : 0.0;
+    for (int i = 0; i < 6; ++i) Jp_out[6 * s + i] = Jp[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_schur_init: S diagonal <- U (undamped), rhs <- gc, Udiag <- diag(U); gradient inf-norm of the
+// camera part.  One thread per free camera.  (S was zeroed by a memset node.)
+__global__ __launch_bounds__(256) void k_schur_init(DeviceProblem d) {
+  __shared__ double red[4];
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  double gmax = 0.0;
+  if (f < d.Cf) {
+    const int cam = d.free2cam[f];
+    const double* u = d.Ugc + (long)cam * 27;
+    double* Sd = d.S + (long)d.diag_slot[f] * 36;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) Sd[6 * i + c] = u[i <= c ? sym6_index(i, c) : sym6_index(c, i)];
+      d.Udiag[6 * f + i] = u[sym6_index(i, i)];
+      const double g = u[21 + i];
+      d.rhs[6 * f + i] = g;
+      gmax = fmax(gmax, fabs(g));
+    }
+  }
+  const double bg = block_max_256(gmax, red);
+  if (threadIdx.x == 0) atomic_max_nonneg(&d.scal[SC_GINF], bg);
+}
+
+// Find the upper-triangle slot of block (fa, fb), fa <= fb, by binary search in row fa.
+__device__ __forceinline__ int upper_slot(const DeviceProblem& d, int fa, int fb) {
+  int lo = d.urow_ptr[fa], hi = d.urow_ptr[fa + 1] - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (d.ucol[mid] < fb) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_schur: reduced camera system, built per landmark track.
+//   S[ca][cb] -= (W_a Vd^-1) W_b^T   for every pair a <= b of the track,   rhs[ca] -= (W_a Vd^-1) gp
+// One group of G lanes walks a contiguous range of tracks; lane p of the group owns pair
+// (a, b) = column-major upper enumeration p = b (b + 1) / 2 + a, which does not depend on the track
+// length, so along a run of tracks with the same camera signature a lane keeps adding into the same
+// S block: the 6x6 product is accumulated in registers and flushed with one fp64 atomic per entry
+// per run.  Algorithmic bytes: W 144 B/obs (each W is re-read by the lanes of its track from L1/L2),
+// V 48 + gp 24 B/landmark, 4 B/obs camera index; S writes 288 B per (pair, run).
+template <int G>
+__global__ __launch_bounds__(256) void k_schur(DeviceProblem d, double lam, double min_diag, int lm_per_group) {
+  const int lane = threadIdx.x & (G - 1);
+  const long group = ((long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const long j0 = group * lm_per_group;
+  const long j1 = min((long)d.L_obs, j0 + lm_per_group);
+  const long n = d.n;
+  double acc[36], accr[6];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) accr[i] = 0.0;
+  int cur_a = -1, cur_b = -1;
+  bool cur_sym = false;
+  int nbad = 0;
+
+  auto flush = [&]() {
+    if (cur_a < 0) return;
+    double* Sb = d.S + (long)upper_slot(d, cur_a, cur_b) * 36;
+    if (cur_sym) {  // two observations of one landmark in the same image: add block + block^T
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) atomic_add_f64(&Sb[6 * i + c], -(acc[6 * i + c] + acc[6 * c + i]));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 36; ++i) atomic_add_f64(&Sb[i], -acc[i]);
+    }
+    if (cur_a == cur_b && !cur_sym) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) atomic_add_f64(&d.rhs[6 * cur_a + i], -accr[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) accr[i] = 0.0;
+  };
+
+  for (long j = j0; j < j1; ++j) {
+    const int kb = d.lm_ptr[j];
+    const int len = d.lm_ptr[j + 1] - kb;
+    const int npairs = len * (len + 1) / 2;
+    double v[6], vi[6], g[3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = d.V[(long)i * d.L + j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g[i] = d.gp[(long)i * d.L + j];
+    const double det = damped_inv3(v, lam, min_diag, vi);
+    if (!(det > 0.0) && lane == 0) ++nbad;
+    for (int p = lane; p < npairs; p += G) {
+      // decode p = b (b + 1) / 2 + a,  a <= b
+      int b = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
+      while ((b + 1) * (b + 2) / 2 <= p) ++b;
+      while (b * (b + 1) / 2 > p) --b;
+      const int a = p - b * (b + 1) / 2;
+      const int ka = kb + a, kbb = kb + b;
+      const int fa = d.cam2free[d.o_cam[ka]], fb = d.cam2free[d.o_cam[kbb]];
+      if (fa < 0 || fb < 0) continue;
+      const bool sym = (fa == fb) && (a != b);
+      if (fa != cur_a || fb != cur_b || sym != cur_sym) {
+        flush();
+        cur_a = fa; cur_b = fb; cur_sym = sym;
+      }
+      double Y[18];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const double w[3] = {d.W[(long)(3 * i) * n + ka], d.W[(long)(3 * i + 1) * n + ka],
+                             d.W[(long)(3 * i + 2) * n + ka]};
+        sym3_mul(vi, w, &Y[3 * i]);
+      }
+      if (a == b) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) accr[i] += Y[3 * i] * g[0] + Y[3 * i + 1] * g[1] + Y[3 * i + 2] * g[2];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const double w0 = d.W[(long)(3 * c) * n + kbb], w1 = d.W[(long)(3 * c + 1) * n + kbb],
+                     w2 = d.W[(long)(3 * c + 2) * n + kbb];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[6 * i + c] += Y[3 * i] * w0 + Y[3 * i + 1] * w1 + Y[3 * i + 2] * w2;
+      }
+    }
+  }
+  flush();
+  if (nbad) atomic_add_f64(&d.scal[SC_BADV], (double)nbad);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_damp_mirror: (after the optional all-reduce) add lam * max(diag U, min_diag) to the diagonal of S,
+// invert the diagonal blocks into the block-Jacobi preconditioner, copy upper off-diagonal blocks,
+// transposed, into their lower mirror slots.  One thread per upper slot.
+__global__ __launch_bounds__(256) void k_damp_mirror(DeviceProblem d, double lam, double min_diag) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.nu) return;
+  double* Sb = d.S + (long)s * 36;
+  const int low = d.low_of[s];
+  if (low >= 0) {
+    double* Sl = d.S + (long)low * 36;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) Sl[6 * c + i] = Sb[6 * i + c];
+  } else {
+    const int f = d.urow[s];
+    double A[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) A[i] = Sb[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) A[7 * i] += lam * fmax(d.Udiag[6 * f + i], min_diag);
+#pragma unroll
+    for (int i = 0; i < 36; ++i) Sb[i] = A[i];
+    if (!spd_inverse6(A)) atomic_add_f64(&d.scal[SC_BADV], 1.0);
+#pragma unroll
+    for (int i = 0; i < 36; ++i) d.Minv[(long)f * 36 + i] = A[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block-Jacobi PCG on S dc = -rhs.  Vectors are [Cf][6]; one thread per scalar row.
+// All step lengths are computed on the device from reduced scalars; the host only polls SC_DONE.
+__global__ __launch_bounds__(256) void k_pcg_init(DeviceProblem d) {
+  __shared__ double red[4];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  double rz = 0.0;
+  if (t < 6 * d.Cf) {
+    const int f = t / 6, i = t - 6 * f;
+    double zi = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) zi += d.Minv[(long)f * 36 + 6 * i + c] * (-d.rhs[6 * f + c]);
+    const double ri = -d.rhs[t];
+    d.dc[t] = 0.0;
+    d.r[t] = ri;
+    d.z[t] = zi;
+    d.p[t] = zi;
+    rz = ri * zi;
+  }
+  const double b = block_sum_256(rz, red);
+  if (threadIdx.x == 0) {
+    atomic_add_f64(&d.scal[SC_RZ], b);
+    atomic_add_f64(&d.scal[SC_RZ0], b);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pcg_spmv(DeviceProblem d) {
+  __shared__ double red[4];
+  if (d.scal[SC_DONE] != 0.0) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  double pq = 0.0;
+  if (t < 6 * d.Cf) {
+    const int f = t / 6, i = t - 6 * f;
+    double s = 0.0;
+    for (int e = d.brow_ptr[f]; e < d.brow_ptr[f + 1]; ++e) {
+      const double* B = d.S + (long)d.bslot[e] * 36 + 6 * i;
+      const double* x = d.p + 6 * d.bcol[e];
+      s += B[0] * x[0] + B[1] * x[1] + B[2] * x[2] + B[3] * x[3] + B[4] * x[4] + B[5] * x[5];
+    }
+    d.q[t] = s;
+    pq = s * d.p[t];
+  }
+  const double b = block_sum_256(pq, red);
+  if (threadIdx.x == 0) atomic_add_f64(&d.scal[SC_PQ], b);
+}
+
+__global__ __launch_bounds__(256) void k_pcg_update(DeviceProblem d) {
+  __shared__ double red[4];
+  if (d.scal[SC_DONE] != 0.0) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const double pq = d.scal[SC_PQ];
+  const double alpha = pq > 0.0 ? d.scal[SC_RZ] / pq : 0.0;
+  double rz = 0.0;
+  if (t < 6 * d.Cf) {
+    const int f = t / 6, i = t - 6 * f;
+    double rn[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) rn[c] = d.r[6 * f + c] - alpha * d.q[6 * f + c];
+    double zi = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) zi += d.Minv[(long)f * 36 + 6 * i + c] * rn[c];
+    d.dc[t] += alpha * d.p[t];
+    d.z[t] = zi;
+    rz = rn[i] * zi;
+    // r is rewritten by k_pcg_dir (all threads of this kernel still read the old r)
+  }
+  const double b = block_sum_256(rz, red);
+  if (threadIdx.x == 0) atomic_add_f64(&d.scal[SC_RZNEW], b);
+}
+
+__global__ __launch_bounds__(256) void k_pcg_dir(DeviceProblem d, double tol2, int max_iter) {
+  if (d.scal[SC_DONE] != 0.0) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const double pq = d.scal[SC_PQ];
+  const double rz = d.scal[SC_RZ], rzn = d.scal[SC_RZNEW];
+  const double alpha = pq > 0.0 ? rz / pq : 0.0;
+  const double beta = rz > 0.0 ? rzn / rz : 0.0;
+  if (t < 6 * d.Cf) {
+    d.r[t] -= alpha * d.q[t];
+    d.p[t] = d.z[t] + beta * d.p[t];
+  }
+  // the scalar roll-over is done by the LAST block to get here, so nobody still reads the old values
+  __shared__ int last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned int ticket = atomicAdd(reinterpret_cast<unsigned int*>(&d.scal[SC_COUNT - 1]), 1u);
+    last = (ticket == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    const double it = d.scal[SC_PCGIT] + 1.0;
+    d.scal[SC_PCGIT] = it;
+    d.scal[SC_RZ] = rzn;
+    d.scal[SC_RZNEW] = 0.0;
+    d.scal[SC_PQ] = 0.0;
+    *reinterpret_cast<unsigned int*>(&d.scal[SC_COUNT - 1]) = 0u;
+    if (!(rzn > tol2 * d.scal[SC_RZ0]) || !(pq > 0.0) || it >= (double)max_iter) d.scal[SC_DONE] = 1.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_pose_update: trial poses = retract(poses, dc); camera part of the step statistics
+// (g.d, d^T U d, |d|^2, |x|^2).  One thread per camera.
+__global__ __launch_bounds__(256) void k_pose_update(DeviceProblem d, const double* __restrict__ poses,
+                                                     double* __restrict__ poses_t) {
+  __shared__ double red[4];
+  const int cam = blockIdx.x * blockDim.x + threadIdx.x;
+  double gd = 0.0, dhd = 0.0, dn = 0.0, xn = 0.0;
+  if (cam < d.C) {
+    const int f = d.cam2free[cam];
+    const double* ps = poses + 7 * cam;
+    double* pt = poses_t + 7 * cam;
+    if (f < 0) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i) pt[i] = ps[i];
+    } else {
+      double dl[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dl[i] = d.dc[6 * f + i];
+      const double* u = d.Ugc + (long)cam * 27;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        gd += u[21 + i] * dl[i];
+        dn += dl[i] * dl[i];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) dhd += dl[i] * u[i <= c ? sym6_index(i, c) : sym6_index(c, i)] * dl[c];
+      }
+      pt[0] = ps[0] + dl[0]; pt[1] = ps[1] + dl[1]; pt[2] = ps[2] + dl[2];
+      // q <- normalise(q (x) [1, dtheta / 2])   (Hamilton product, reference src/geometry.py:504-512)
+      const double w1 = ps[3], x1 = ps[4], y1 = ps[5], z1 = ps[6];
+      const double x2 = 0.5 * dl[3], y2 = 0.5 * dl[4], z2 = 0.5 * dl[5];
+      double w = w1 - x1 * x2 - y1 * y2 - z1 * z2;
+      double x = w1 * x2 + x1 + y1 * z2 - z1 * y2;
+      double y = w1 * y2 - x1 * z2 + y1 + z1 * x2;
+      double z = w1 * z2 + x1 * y2 - y1 * x2 + z1;
+      const double inv = 1.0 / sqrt(w * w + x * x + y * y + z * z);
+      pt[3] = w * inv; pt[4] = x * inv; pt[5] = y * inv; pt[6] = z * inv;
+      xn = ps[0] * ps[0] + ps[1] * ps[1] + ps[2] * ps[2] + 1.0;
+    }
+  }
+  const double b0 = block_sum_256(gd, red), b1 = block_sum_256(dhd, red), b2 = block_sum_256(dn, red),
+               b3 = block_sum_256(xn, red);
+  if (threadIdx.x == 0) {
+    atomic_add_f64(&d.scal[SC_GDOT], b0);
+    atomic_add_f64(&d.scal[SC_DHD], b1);
+    atomic_add_f64(&d.scal[SC_DNORM2], b2);
+    atomic_add_f64(&d.scal[SC_XNORM2], b3);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_backsub: dp_j = -Vd_j^-1 (gp_j + sum_k W_k^T dc_cam(k)),  trial point = P_j + dp_j, and the
+// point part of the step statistics (g.d, d^T V d + 2 dc^T W dp, |d|^2, |x|^2).
+// Same group-per-track walk as k_linearize.  Algorithmic bytes: W 144 B/obs + 4 B/obs,
+// per landmark V 48 + gp 24 + P 24 read, P 24 written.
+template <int G>
+__global__ __launch_bounds__(256) void k_backsub(DeviceProblem d, double lam, double min_diag,
+                                                 const double* __restrict__ pts, double* __restrict__ pts_t,
+                                                 int lm_per_group) {
+  __shared__ double red[4];
+  const int lane = threadIdx.x & (G - 1);
+  const long group = ((long)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  const long j0 = group * lm_per_group;
+  const long j1 = min((long)d.L_obs, j0 + lm_per_group);
+  const long n = d.n;
+  double gd = 0.0, dhd = 0.0, dn = 0.0, xn = 0.0;
+  for (long j = j0; j < j1; ++j) {
+    const int kb = d.lm_ptr[j], ke = d.lm_ptr[j + 1];
+    double t[3] = {0, 0, 0};
+    for (int k = kb + lane; k < ke; k += G) {
+      const int f = d.cam2free[d.o_cam[k]];
+      if (f < 0) continue;
+      double dl[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dl[i] = d.dc[6 * f + i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t[c] += d.W[(long)(3 * i + c) * n + k] * dl[i];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) t[c] = group_sum<G>(t[c]);
+    if (lane == 0) {
+      double v[6], vi[6], g[3], s[3], dp[3];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) v[i] = d.V[(long)i * d.L + j];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) g[i] = d.gp[(long)i * d.L + j];
+      damped_inv3(v, lam, min_diag, vi);
+      s[0] = g[0] + t[0]; s[1] = g[1] + t[1]; s[2] = g[2] + t[2];
+      sym3_mul(vi, s, dp);
+      dp[0] = -dp[0]; dp[1] = -dp[1]; dp[2] = -dp[2];
+      const double P[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
+      pts_t[3 * j] = P[0] + dp[0]; pts_t[3 * j + 1] = P[1] + dp[1]; pts_t[3 * j + 2] = P[2] + dp[2];
+      gd += g[0] * dp[0] + g[1] * dp[1] + g[2] * dp[2];
+      const double vdp0 = v[0] * dp[0] + v[1] * dp[1] + v[2] * dp[2];
+      const double vdp1 = v[1] * dp[0] + v[3] * dp[1] + v[4] * dp[2];
+      const double vdp2 = v[2] * dp[0] + v[4] * dp[1] + v[5] * dp[2];
+      dhd += dp[0] * vdp0 + dp[1] * vdp1 + dp[2] * vdp2 + 2.0 * (t[0] * dp[0] + t[1] * dp[1] + t[2] * dp[2]);
+      dn += dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];
+      xn += P[0] * P[0] + P[1] * P[1] + P[2] * P[2];
+    }
+  }
+  const double b0 = block_sum_256(gd, red), b1 = block_sum_256(dhd, red), b2 = block_sum_256(dn, red),
+               b3 = block_sum_256(xn, red);
+  if (threadIdx.x == 0) {
+    atomic_add_f64(&d.scal[SC_GDOT], b0);
+    atomic_add_f64(&d.scal[SC_DHD], b1);
+    atomic_add_f64(&d.scal[SC_DNORM2], b2);
+    atomic_add_f64(&d.scal[SC_XNORM2], b3);
+  }
+}
+
+// Copy the untouched (unobserved) landmarks [L_obs, L) into the trial buffer.
+__global__ void k_copy_tail(const double* __restrict__ src, double* __restrict__ dst, long begin, long end) {
+  for (long i = begin + (long)blockIdx.x * blockDim.x + threadIdx.x; i < end; i += (long)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}

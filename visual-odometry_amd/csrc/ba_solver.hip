@@ -1,0 +1,797 @@
+// Host side of libba_amd.so: problem set-up (track sort, Schur block pattern), the
+// Levenberg-Marquardt driver and the extern "C" entry points declared in include/ba_amd.h.
+// Replaces the scipy least_squares call of reference src/bundle_adjustment.py:201-219.
+#include "../../include/ba_amd.h"
+#include "ba_kernels.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+namespace {
+
+using clk = std::chrono::steady_clock;
+inline double ms_since(clk::time_point t0) {
+  return std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+}
+
+struct DevBuf {  // owning device allocation
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+struct ba_handle {
+  ba_options opt;
+  std::string err;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool has_problem = false, has_guess = false, has_estimate = false;
+  double setup_ms = 0.0;
+
+  // host copies of the structure
+  int C = 0, Cf = 0, L = 0, L_obs = 0, n = 0;
+  std::vector<int> lm_internal_to_user, lm_user_to_internal;  // landmark permutation
+  std::vector<int> obs_src;                                   // internal obs k -> caller's index
+  std::vector<int> cam2free, free2cam;
+  std::vector<int> urow_ptr, ucol;
+  std::vector<uint8_t> fixed;
+  int g_lin = 16, g_schur = 64, lpg_lin = 1, lpg_schur = 1;
+
+  DeviceProblem d{};
+  std::vector<void*> allocs;  // everything to hipFree
+  double *poses_cur = nullptr, *poses_trial = nullptr, *poses_init = nullptr;
+  double *pts_cur = nullptr, *pts_trial = nullptr, *pts_init = nullptr;
+  double* scal_host = nullptr;  // pinned
+  double* stage = nullptr;      // pinned staging for pose / point transfers
+  size_t stage_bytes = 0;
+};
+
+namespace {
+
+int fail(ba_handle* h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                                        \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return fail(h, e_ == hipErrorOutOfMemory ? BA_ERR_NOMEM : BA_ERR_DEVICE, "%s failed: %s", \
+                  #expr, hipGetErrorString(e_));                                                \
+  } while (0)
+
+void free_problem(ba_handle* h) {
+  for (void* p : h->allocs) (void)hipFree(p);
+  h->allocs.clear();
+  if (h->stage) (void)hipHostFree(h->stage);
+  h->stage = nullptr;
+  h->stage_bytes = 0;
+  h->has_problem = h->has_guess = h->has_estimate = false;
+  h->d = DeviceProblem{};
+}
+
+template <class T>
+int dev_alloc(ba_handle* h, T** out, size_t count) {
+  void* p = nullptr;
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  HIP_TRY(h, hipMalloc(&p, bytes));
+  h->allocs.push_back(p);
+  *out = static_cast<T*>(p);
+  return BA_OK;
+}
+
+template <class T>
+int dev_upload(ba_handle* h, const T** out, const std::vector<T>& v) {
+  T* p = nullptr;
+  int rc = dev_alloc(h, &p, v.size());
+  if (rc) return rc;
+  if (!v.empty()) HIP_TRY(h, hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = p;
+  return BA_OK;
+}
+
+int pow2_at_least(int v, int lo, int hi) {
+  int g = lo;
+  while (g < v && g < hi) g <<= 1;
+  return g;
+}
+
+int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+inline int grid_for(long items, int block = 256) { return (int)std::max<long>(1, (items + block - 1) / block); }
+
+// ---------------------------------------------------------------------------------------------- launches
+void launch_linearize(ba_handle* h, const double* poses, const double* pts) {
+  const DeviceProblem& d = h->d;
+  const long groups = (d.L_obs + h->lpg_lin - 1) / h->lpg_lin;
+  const int G = h->g_lin;
+  const int grid = grid_for(groups * G);
+  switch (G) {
+    case 8: k_linearize<8><<<grid, 256, 0, h->stream>>>(d, poses, pts, h->lpg_lin); break;
+    case 16: k_linearize<16><<<grid, 256, 0, h->stream>>>(d, poses, pts, h->lpg_lin); break;
+    case 32: k_linearize<32><<<grid, 256, 0, h->stream>>>(d, poses, pts, h->lpg_lin); break;
+    default: k_linearize<64><<<grid, 256, 0, h->stream>>>(d, poses, pts, h->lpg_lin); break;
+  }
+}
+
+void launch_backsub(ba_handle* h, double lam, const double* pts, double* pts_t) {
+  const DeviceProblem& d = h->d;
+  const long groups = (d.L_obs + h->lpg_lin - 1) / h->lpg_lin;
+  const int G = h->g_lin;
+  const int grid = grid_for(groups * G);
+  const double md = h->opt.min_diag;
+  switch (G) {
+    case 8: k_backsub<8><<<grid, 256, 0, h->stream>>>(d, lam, md, pts, pts_t, h->lpg_lin); break;
+    case 16: k_backsub<16><<<grid, 256, 0, h->stream>>>(d, lam, md, pts, pts_t, h->lpg_lin); break;
+    case 32: k_backsub<32><<<grid, 256, 0, h->stream>>>(d, lam, md, pts, pts_t, h->lpg_lin); break;
+    default: k_backsub<64><<<grid, 256, 0, h->stream>>>(d, lam, md, pts, pts_t, h->lpg_lin); break;
+  }
+}
+
+void launch_schur(ba_handle* h, double lam) {
+  const DeviceProblem& d = h->d;
+  const long groups = (d.L_obs + h->lpg_schur - 1) / h->lpg_schur;
+  const int G = h->g_schur;
+  const int grid = grid_for(groups * G);
+  const double md = h->opt.min_diag;
+  switch (G) {
+    case 8: k_schur<8><<<grid, 256, 0, h->stream>>>(d, lam, md, h->lpg_schur); break;
+    case 16: k_schur<16><<<grid, 256, 0, h->stream>>>(d, lam, md, h->lpg_schur); break;
+    case 32: k_schur<32><<<grid, 256, 0, h->stream>>>(d, lam, md, h->lpg_schur); break;
+    default: k_schur<64><<<grid, 256, 0, h->stream>>>(d, lam, md, h->lpg_schur); break;
+  }
+}
+
+void launch_cost(ba_handle* h, const double* poses, const double* pts, int cost_slot, int behind_slot,
+                 double* res_out) {
+  const int grid = std::min(grid_for(h->d.n), 256 * 16);
+  k_cost<<<grid, 256, 0, h->stream>>>(h->d, poses, pts, cost_slot, behind_slot, res_out);
+}
+
+// linearise at (poses, pts): zero accumulators, blocks U V W gc gp, cost into scal[SC_COST]
+int do_linearize(ba_handle* h, const double* poses, const double* pts) {
+  HIP_TRY(h, hipMemsetAsync(h->d.scal, 0, SC_COUNT * sizeof(double), h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d.Ugc, 0, (size_t)h->C * 27 * sizeof(double), h->stream));
+  launch_linearize(h, poses, pts);
+  return BA_OK;
+}
+
+// build S / rhs for damping lam, precondition, solve for dc by block-Jacobi PCG
+int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
+  DeviceProblem& d = h->d;
+  const ba_options& o = h->opt;
+  HIP_TRY(h, hipMemsetAsync(d.S, 0, (size_t)(d.nu + d.nl) * 36 * sizeof(double), h->stream));
+  k_schur_init<<<grid_for(d.Cf), 256, 0, h->stream>>>(d);
+  launch_schur(h, lam);
+  k_damp_mirror<<<grid_for(d.nu), 256, 0, h->stream>>>(d, lam, o.min_diag);
+  const int gv = grid_for(6L * d.Cf);
+  k_pcg_init<<<gv, 256, 0, h->stream>>>(d);
+  const double tol2 = o.pcg_tol * o.pcg_tol;
+  const int every = std::max(1, o.pcg_check_every);
+  int launched = 0;
+  while (launched < o.pcg_max_iter) {
+    const int nb = std::min(every, o.pcg_max_iter - launched);
+    for (int i = 0; i < nb; ++i) {
+      k_pcg_spmv<<<gv, 256, 0, h->stream>>>(d);
+      k_pcg_update<<<gv, 256, 0, h->stream>>>(d);
+      k_pcg_dir<<<gv, 256, 0, h->stream>>>(d, tol2, o.pcg_max_iter);
+    }
+    launched += nb;
+    HIP_TRY(h, hipMemcpyAsync(h->scal_host + SC_RZ, d.scal + SC_RZ, 8 * sizeof(double), hipMemcpyDeviceToHost,
+                              h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->scal_host[SC_DONE] != 0.0) break;
+  }
+  *pcg_iters = (int)h->scal_host[SC_PCGIT];
+  return BA_OK;
+}
+
+// step statistics + trial state + trial cost; leaves everything in scal
+int do_trial(ba_handle* h, double lam, const double* poses, const double* pts, double* poses_t, double* pts_t) {
+  DeviceProblem& d = h->d;
+  k_pose_update<<<grid_for(d.C), 256, 0, h->stream>>>(d, poses, poses_t);
+  launch_backsub(h, lam, pts, pts_t);
+  launch_cost(h, poses_t, pts_t, SC_COST_T, SC_NBEHIND_T, nullptr);
+  HIP_TRY(h, hipMemcpyAsync(h->scal_host, d.scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return BA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- transfers
+// Quaternion handling follows the reference: free poses are normalised (bundle_adjustment.py:63),
+// the fixed pose only when its norm is off by more than 1e-6 (geometry.py:189-190).
+int stage_state(ba_handle* h, const double* poses, const double* points, double* d_poses, double* d_pts) {
+  double* sp = h->stage;
+  double* sx = h->stage + (size_t)h->C * 7;
+  for (int c = 0; c < h->C; ++c) {
+    const double* p = poses + 7 * c;
+    for (int i = 0; i < 7; ++i)
+      if (!std::isfinite(p[i])) return fail(h, BA_ERR_INVALID, "pose %d has a non-finite entry", c);
+    const double nq = std::sqrt(p[3] * p[3] + p[4] * p[4] + p[5] * p[5] + p[6] * p[6]);
+    if (nq == 0.0) return fail(h, BA_ERR_INVALID, "pose %d has a zero quaternion", c);
+    const bool renorm = !h->fixed[c] || std::fabs(nq - 1.0) > 1e-6;
+    for (int i = 0; i < 3; ++i) sp[7 * c + i] = p[i];
+    for (int i = 3; i < 7; ++i) sp[7 * c + i] = renorm ? p[i] / nq : p[i];
+  }
+  for (int j = 0; j < h->L; ++j) {
+    const double* x = points + 3 * (size_t)h->lm_internal_to_user[j];
+    if (!std::isfinite(x[0]) || !std::isfinite(x[1]) || !std::isfinite(x[2]))
+      return fail(h, BA_ERR_INVALID, "landmark %d has a non-finite coordinate", h->lm_internal_to_user[j]);
+    sx[3 * (size_t)j] = x[0]; sx[3 * (size_t)j + 1] = x[1]; sx[3 * (size_t)j + 2] = x[2];
+  }
+  HIP_TRY(h, hipMemcpyAsync(d_poses, sp, (size_t)h->C * 7 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(d_pts, sx, (size_t)h->L * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return BA_OK;
+}
+
+int fetch_state(ba_handle* h, const double* d_poses, const double* d_pts, double* poses, double* points) {
+  double* sp = h->stage;
+  double* sx = h->stage + (size_t)h->C * 7;
+  HIP_TRY(h, hipMemcpyAsync(sp, d_poses, (size_t)h->C * 7 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(sx, d_pts, (size_t)h->L * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (int c = 0; c < h->C; ++c)
+    if (!h->fixed[c]) std::memcpy(poses + 7 * c, sp + 7 * c, 7 * sizeof(double));
+  for (int j = 0; j < h->L_obs; ++j)  // unobserved landmarks are left untouched
+    std::memcpy(points + 3 * (size_t)h->lm_internal_to_user[j], sx + 3 * (size_t)j, 3 * sizeof(double));
+  return BA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- LM driver
+int lm_solve(ba_handle* h, ba_report* rep) {
+  const ba_options& o = h->opt;
+  DeviceProblem& d = h->d;
+  std::memset(rep, 0, sizeof *rep);
+  rep->nobs = h->n;
+  rep->setup_ms = h->setup_ms;
+  const size_t pose_bytes = (size_t)h->C * 7 * sizeof(double), pts_bytes = (size_t)h->L * 3 * sizeof(double);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  const auto t0 = clk::now();
+  HIP_TRY(h, hipMemcpyAsync(h->poses_cur, h->poses_init, pose_bytes, hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->pts_cur, h->pts_init, pts_bytes, hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->pts_trial, h->pts_init, pts_bytes, hipMemcpyDeviceToDevice, h->stream));
+  double* poses = h->poses_cur;
+  double* poses_t = h->poses_trial;
+  double* pts = h->pts_cur;
+  double* pts_t = h->pts_trial;
+
+  double lam = o.lambda0, nu = 2.0;
+  double cost = 0.0, nbehind = 0.0, ginf = 0.0;
+  bool need_lin = true;
+  int it = 0, status = BA_STOP_MAX_ITERS;
+  while (it < o.max_iters) {
+    ++it;
+    int rc;
+    if (need_lin) {
+      if ((rc = do_linearize(h, poses, pts))) return rc;
+      rep->linearizations++;
+    } else {
+      HIP_TRY(h, hipMemsetAsync(d.scal, 0, SC_COUNT * sizeof(double), h->stream));
+    }
+    int pcg_it = 0;
+    if ((rc = do_reduced_solve(h, lam, &pcg_it))) return rc;
+    if ((rc = do_trial(h, lam, poses, pts, poses_t, pts_t))) return rc;
+    const double* s = h->scal_host;
+    if (need_lin) {
+      cost = s[SC_COST];
+      nbehind = s[SC_NBEHIND];
+      ginf = s[SC_GINF];
+      if (it == 1) {
+        rep->cost0 = cost;
+        if (s[SC_ZEROZ] > 0.0)
+          return fail(h, BA_ERR_NUMERICAL, "cannot project points with zero Z coordinates (division by zero)");
+        if (!std::isfinite(cost)) return fail(h, BA_ERR_NUMERICAL, "non-finite cost at the initial guess");
+      }
+      need_lin = false;
+    }
+    rep->pcg_iters += pcg_it;
+    rep->grad_inf = ginf;
+    if (ginf <= o.gtol) {
+      status = BA_STOP_GTOL;
+      break;
+    }
+    const double cost_t = s[SC_COST_T];
+    const double pred = -s[SC_GDOT] - 0.5 * s[SC_DHD];
+    double rho = (pred > 0.0 && std::isfinite(cost_t)) ? (cost - cost_t) / pred : -1.0;
+    if (o.guard_cheirality && s[SC_NBEHIND_T] > nbehind) rho = -1.0;
+    const double step_norm = std::sqrt(s[SC_DNORM2]);
+    const double x_norm = std::sqrt(s[SC_XNORM2]);
+    const bool accept = rho > o.accept_ratio;
+    const int hi = rep->n_history < BA_HISTORY ? rep->n_history++ : BA_HISTORY - 1;
+    rep->lambda_history[hi] = lam;
+    rep->pcg_history[hi] = pcg_it;
+    rep->accepted_history[hi] = accept;
+    if (o.verbose)
+      fprintf(stderr, "[ba] it %3d cost %.12e trial %.12e rho %8.3g lam %.2e |g| %.2e |dx| %.2e pcg %d %s\n", it, cost,
+              cost_t, rho, lam, ginf, step_norm, pcg_it, accept ? "accept" : "reject");
+    bool stop = false;
+    if (accept) {
+      const double dF = cost - cost_t;
+      std::swap(poses, poses_t);
+      std::swap(pts, pts_t);
+      cost = cost_t;
+      nbehind = s[SC_NBEHIND_T];
+      rep->accepted++;
+      lam = std::max(o.lambda_min, lam * std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3)));
+      nu = 2.0;
+      need_lin = true;
+      if (dF <= o.ftol * cost) { status = BA_STOP_FTOL; stop = true; }
+      else if (step_norm <= o.xtol * (x_norm + o.xtol)) { status = BA_STOP_XTOL; stop = true; }
+    } else {
+      lam = std::min(o.lambda_max, lam * nu);
+      nu *= 2.0;
+      if (step_norm <= o.xtol * (x_norm + o.xtol)) { status = BA_STOP_XTOL; stop = true; }
+    }
+    rep->cost_history[hi] = cost;
+    if (stop) break;
+  }
+  // the estimate lives in (poses, pts); make poses_cur / pts_cur point at it
+  if (poses != h->poses_cur) std::swap(h->poses_cur, h->poses_trial);
+  if (pts != h->pts_cur) std::swap(h->pts_cur, h->pts_trial);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  rep->solve_ms = ms_since(t0);
+  rep->cost = cost;
+  rep->lambda = lam;
+  rep->iterations = it;
+  rep->status = status;
+  rep->rms_reproj = h->n > 0 ? std::sqrt(2.0 * cost / h->n) : 0.0;
+  h->has_estimate = true;
+  return BA_OK;
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+int ba_version(void) { return BA_AMD_VERSION; }
+
+int ba_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void ba_default_options(ba_options* o) {
+  if (!o) return;
+  o->max_iters = 200;
+  o->ftol = 1e-10;
+  o->xtol = 1e-12;
+  o->gtol = 1e-10;
+  o->lambda0 = 1e-4;
+  o->lambda_min = 1e-12;
+  o->lambda_max = 1e12;
+  o->min_diag = 1e-12;
+  o->accept_ratio = 1e-4;
+  o->guard_cheirality = 1;
+  o->linear_solver = BA_SOLVER_AUTO;
+  o->pcg_tol = 1e-2;
+  o->pcg_max_iter = 1000;
+  o->pcg_check_every = 10;
+  o->device = -1;
+  o->verbose = 0;
+}
+
+int ba_create(const ba_options* opt, ba_handle** out) {
+  if (!out) return BA_ERR_INVALID;
+  *out = nullptr;
+  ba_handle* h = new (std::nothrow) ba_handle();
+  if (!h) return BA_ERR_NOMEM;
+  if (opt) h->opt = *opt; else ba_default_options(&h->opt);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    delete h;
+    return BA_ERR_DEVICE;  // no GPU: the product path fails loudly, there is no CPU fallback
+  }
+  int dev = h->opt.device;
+  if (dev < 0) (void)hipGetDevice(&dev);
+  if (dev >= ndev) { delete h; return BA_ERR_INVALID; }
+  h->device = dev;
+  if (hipSetDevice(dev) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess ||
+      hipHostMalloc((void**)&h->scal_host, SC_COUNT * sizeof(double)) != hipSuccess) {
+    delete h;
+    return BA_ERR_DEVICE;
+  }
+  *out = h;
+  return BA_OK;
+}
+
+void ba_destroy(ba_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  free_problem(h);
+  if (h->scal_host) (void)hipHostFree(h->scal_host);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+const char* ba_last_error(const ba_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int ba_schur_block_count(const ba_handle* h, int64_t* nu) {
+  if (!h || !nu || !h->has_problem) return BA_ERR_STATE;
+  *nu = h->d.nu;
+  return BA_OK;
+}
+
+int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t* obs_cam, const int32_t* obs_pt,
+                   const double* obs_uv, const double* intr, const uint8_t* fixed_in) {
+  if (!h) return BA_ERR_INVALID;
+  if (C <= 0 || L <= 0 || n <= 0 || !obs_cam || !obs_pt || !obs_uv || !intr)
+    return fail(h, BA_ERR_INVALID, "set_problem: empty problem or null pointer (C=%d L=%d n=%d)", C, L, n);
+  for (int i = 0; i < 7; ++i)
+    if (!std::isfinite(intr[i])) return fail(h, BA_ERR_INVALID, "intrinsics[%d] is not finite", i);
+  if (!(intr[0] > 0) || !(intr[1] > 0)) return fail(h, BA_ERR_INVALID, "focal lengths must be positive");
+  const auto t0 = clk::now();
+  HIP_TRY(h, hipSetDevice(h->device));
+  free_problem(h);
+  h->C = C; h->L = L; h->n = n;
+
+  // ---- cameras
+  h->fixed.assign(C, 0);
+  if (fixed_in) { for (int c = 0; c < C; ++c) h->fixed[c] = fixed_in[c] ? 1 : 0; } else h->fixed[0] = 1;
+  h->cam2free.assign(C, -1);
+  h->free2cam.clear();
+  for (int c = 0; c < C; ++c)
+    if (!h->fixed[c]) { h->cam2free[c] = (int)h->free2cam.size(); h->free2cam.push_back(c); }
+  h->Cf = (int)h->free2cam.size();
+  if (h->Cf == 0) return fail(h, BA_ERR_INVALID, "every pose is fixed: nothing to optimise");
+  const int Cf = h->Cf;
+
+  // ---- tracks: observations grouped by landmark, camera-sorted inside a track
+  std::vector<int> cnt(L + 1, 0);
+  for (int k = 0; k < n; ++k) {
+    if (obs_cam[k] < 0 || obs_cam[k] >= C) return fail(h, BA_ERR_INVALID, "obs_cam[%d]=%d out of range", k, obs_cam[k]);
+    if (obs_pt[k] < 0 || obs_pt[k] >= L) return fail(h, BA_ERR_INVALID, "obs_pt[%d]=%d out of range", k, obs_pt[k]);
+    if (!std::isfinite(obs_uv[2 * (size_t)k]) || !std::isfinite(obs_uv[2 * (size_t)k + 1]))
+      return fail(h, BA_ERR_INVALID, "observation %d is not finite", k);
+    cnt[obs_pt[k] + 1]++;
+  }
+  std::vector<int> uptr(L + 1, 0);
+  for (int j = 0; j < L; ++j) uptr[j + 1] = uptr[j] + cnt[j + 1];
+  std::vector<int> track(n);
+  {
+    std::vector<int> fill(uptr.begin(), uptr.end() - 1);
+    for (int k = 0; k < n; ++k) track[fill[obs_pt[k]]++] = k;
+  }
+  for (int j = 0; j < L; ++j)
+    std::sort(track.begin() + uptr[j], track.begin() + uptr[j + 1], [&](int a, int b) {
+      return obs_cam[a] != obs_cam[b] ? obs_cam[a] < obs_cam[b] : a < b;
+    });
+  // ---- landmark order: observed first, lexicographic by camera signature (locality for the
+  //      register run-length accumulation of k_linearize / k_schur), ties by index
+  std::vector<int> order(L);
+  std::iota(order.begin(), order.end(), 0);
+  auto sig_less = [&](int a, int b) {
+    const int la = uptr[a + 1] - uptr[a], lb = uptr[b + 1] - uptr[b];
+    if ((la == 0) != (lb == 0)) return lb == 0;
+    const int m = std::min(la, lb);
+    for (int i = 0; i < m; ++i) {
+      const int ca = obs_cam[track[uptr[a] + i]], cb = obs_cam[track[uptr[b] + i]];
+      if (ca != cb) return ca < cb;
+    }
+    if (la != lb) return la < lb;
+    return a < b;
+  };
+  std::sort(order.begin(), order.end(), sig_less);
+  h->lm_internal_to_user = order;
+  h->lm_user_to_internal.assign(L, 0);
+  for (int j = 0; j < L; ++j) h->lm_user_to_internal[order[j]] = j;
+  int L_obs = 0;
+  while (L_obs < L && uptr[order[L_obs] + 1] > uptr[order[L_obs]]) ++L_obs;
+  h->L_obs = L_obs;
+
+  std::vector<int> o_cam(n), o_src(n), o_lm(n), lm_ptr(L_obs + 1, 0);
+  std::vector<double> o_u(n), o_v(n);
+  {
+    int k2 = 0;
+    for (int j = 0; j < L_obs; ++j) {
+      const int uj = order[j];
+      for (int e = uptr[uj]; e < uptr[uj + 1]; ++e, ++k2) {
+        const int k = track[e];
+        o_cam[k2] = obs_cam[k]; o_src[k2] = k; o_lm[k2] = j;
+        o_u[k2] = obs_uv[2 * (size_t)k]; o_v[k2] = obs_uv[2 * (size_t)k + 1];
+      }
+      lm_ptr[j + 1] = k2;
+    }
+  }
+  h->obs_src = o_src;
+
+  // ---- block pattern of the reduced camera system (upper triangle over free cameras)
+  std::vector<int64_t> keys;
+  for (int f = 0; f < Cf; ++f) keys.push_back((int64_t)f * Cf + f);
+  {
+    std::vector<int> prev, cur;
+    for (int j = 0; j < L_obs; ++j) {
+      cur.clear();
+      for (int k = lm_ptr[j]; k < lm_ptr[j + 1]; ++k) {
+        const int f = h->cam2free[o_cam[k]];
+        if (f >= 0 && (cur.empty() || cur.back() != f)) cur.push_back(f);
+      }
+      if (cur == prev) continue;
+      for (size_t a = 0; a < cur.size(); ++a)
+        for (size_t b = a + 1; b < cur.size(); ++b) keys.push_back((int64_t)cur[a] * Cf + cur[b]);
+      prev.swap(cur);
+      if (keys.size() > (size_t)64 << 20) {  // keep the key list bounded on unstructured scenes
+        std::sort(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+      }
+    }
+  }
+  std::sort(keys.begin(), keys.end());
+  keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  const int nu = (int)keys.size();
+  std::vector<int> urow_ptr(Cf + 1, 0), ucol(nu), urow(nu), diag_slot(Cf), low_of(nu, -1);
+  for (int s = 0; s < nu; ++s) {
+    urow[s] = (int)(keys[s] / Cf);
+    ucol[s] = (int)(keys[s] % Cf);
+    urow_ptr[urow[s] + 1]++;
+    if (urow[s] == ucol[s]) diag_slot[urow[s]] = s;
+  }
+  for (int f = 0; f < Cf; ++f) urow_ptr[f + 1] += urow_ptr[f];
+  int nl = 0;
+  std::vector<int> brow_cnt(Cf + 1, 0);
+  for (int s = 0; s < nu; ++s) {
+    brow_cnt[urow[s] + 1]++;
+    if (urow[s] != ucol[s]) { low_of[s] = nu + nl++; brow_cnt[ucol[s] + 1]++; }
+  }
+  std::vector<int> brow_ptr(Cf + 1, 0);
+  for (int f = 0; f < Cf; ++f) brow_ptr[f + 1] = brow_ptr[f] + brow_cnt[f + 1];
+  const int nb = brow_ptr[Cf];
+  std::vector<int> bcol(nb), bslot(nb);
+  {
+    // lower entries of row i (cols j < i) come from upper slots (j, i): visiting upper slots in
+    // (row, col) order emits them in ascending j, ahead of the row's own upper entries
+    std::vector<int> fill(brow_ptr.begin(), brow_ptr.end() - 1);
+    for (int s = 0; s < nu; ++s)
+      if (urow[s] != ucol[s]) { const int i = ucol[s]; bcol[fill[i]] = urow[s]; bslot[fill[i]++] = low_of[s]; }
+    for (int s = 0; s < nu; ++s) { const int i = urow[s]; bcol[fill[i]] = ucol[s]; bslot[fill[i]++] = s; }
+  }
+  h->urow_ptr = urow_ptr;
+  h->ucol = ucol;
+
+  // ---- launch geometry
+  {
+    std::vector<int> lens(L_obs);
+    for (int j = 0; j < L_obs; ++j) lens[j] = lm_ptr[j + 1] - lm_ptr[j];
+    std::vector<int> tmp(lens);
+    const size_t q = (size_t)(0.9 * (tmp.size() - 1));
+    std::nth_element(tmp.begin(), tmp.begin() + q, tmp.end());
+    const int len90 = std::max(1, tmp[q]);
+    h->g_lin = env_int("BA_G_LIN", pow2_at_least(len90, 8, 64));
+    h->g_schur = env_int("BA_G_SCHUR", pow2_at_least(len90 * (len90 + 1) / 2, 8, 64));
+    const long target_waves = 256L * 8;  // ~8 waves per CU
+    const long groups_lin = target_waves * (64 / h->g_lin), groups_schur = target_waves * (64 / h->g_schur);
+    h->lpg_lin = env_int("BA_LPG_LIN", (int)std::max<long>(1, (L_obs + groups_lin - 1) / groups_lin));
+    h->lpg_schur = env_int("BA_LPG_SCHUR", (int)std::max<long>(1, (L_obs + groups_schur - 1) / groups_schur));
+  }
+
+  // ---- upload structure, allocate state
+  DeviceProblem& d = h->d;
+  d.C = C; d.Cf = Cf; d.L = L; d.L_obs = L_obs; d.n = n;
+  d.K = Intrinsics{intr[0], intr[1], intr[2], intr[3], intr[4], intr[5], intr[6],
+                   (intr[4] != 0.0 || intr[5] != 0.0 || intr[6] != 0.0) ? 1 : 0};
+  d.nu = nu; d.nl = nl; d.nb = nb;
+  int rc;
+  if ((rc = dev_upload(h, &d.o_cam, o_cam)) || (rc = dev_upload(h, &d.o_u, o_u)) || (rc = dev_upload(h, &d.o_v, o_v)) ||
+      (rc = dev_upload(h, &d.o_src, o_src)) || (rc = dev_upload(h, &d.o_lm, o_lm)) ||
+      (rc = dev_upload(h, &d.lm_ptr, lm_ptr)) || (rc = dev_upload(h, &d.cam2free, h->cam2free)) ||
+      (rc = dev_upload(h, &d.free2cam, h->free2cam)) || (rc = dev_upload(h, &d.urow_ptr, urow_ptr)) ||
+      (rc = dev_upload(h, &d.ucol, ucol)) || (rc = dev_upload(h, &d.urow, urow)) ||
+      (rc = dev_upload(h, &d.diag_slot, diag_slot)) || (rc = dev_upload(h, &d.low_of, low_of)) ||
+      (rc = dev_upload(h, &d.brow_ptr, brow_ptr)) || (rc = dev_upload(h, &d.bcol, bcol)) ||
+      (rc = dev_upload(h, &d.bslot, bslot)))
+    return rc;
+  if ((rc = dev_alloc(h, &d.W, (size_t)18 * n)) || (rc = dev_alloc(h, &d.V, (size_t)6 * L)) ||
+      (rc = dev_alloc(h, &d.gp, (size_t)3 * L)) || (rc = dev_alloc(h, &d.Ugc, (size_t)27 * C)) ||
+      (rc = dev_alloc(h, &d.S, (size_t)36 * (nu + nl))) || (rc = dev_alloc(h, &d.rhs, (size_t)6 * Cf)) ||
+      (rc = dev_alloc(h, &d.Udiag, (size_t)6 * Cf)) || (rc = dev_alloc(h, &d.Minv, (size_t)36 * Cf)) ||
+      (rc = dev_alloc(h, &d.dc, (size_t)6 * Cf)) || (rc = dev_alloc(h, &d.r, (size_t)6 * Cf)) ||
+      (rc = dev_alloc(h, &d.z, (size_t)6 * Cf)) || (rc = dev_alloc(h, &d.p, (size_t)6 * Cf)) ||
+      (rc = dev_alloc(h, &d.q, (size_t)6 * Cf)) || (rc = dev_alloc(h, &d.scal, (size_t)SC_COUNT)) ||
+      (rc = dev_alloc(h, &h->poses_cur, (size_t)7 * C)) || (rc = dev_alloc(h, &h->poses_trial, (size_t)7 * C)) ||
+      (rc = dev_alloc(h, &h->poses_init, (size_t)7 * C)) || (rc = dev_alloc(h, &h->pts_cur, (size_t)3 * L)) ||
+      (rc = dev_alloc(h, &h->pts_trial, (size_t)3 * L)) || (rc = dev_alloc(h, &h->pts_init, (size_t)3 * L)))
+    return rc;
+  HIP_TRY(h, hipMemset(d.V, 0, (size_t)6 * L * sizeof(double)));
+  HIP_TRY(h, hipMemset(d.gp, 0, (size_t)3 * L * sizeof(double)));
+  HIP_TRY(h, hipMemset(d.dc, 0, (size_t)6 * Cf * sizeof(double)));
+  h->stage_bytes = ((size_t)7 * C + (size_t)3 * L) * sizeof(double);
+  HIP_TRY(h, hipHostMalloc((void**)&h->stage, h->stage_bytes));
+  HIP_TRY(h, hipDeviceSynchronize());
+  h->has_problem = true;
+  h->setup_ms = ms_since(t0);
+  return BA_OK;
+}
+
+int ba_upload_guess(ba_handle* h, const double* poses, const double* points) {
+  if (!h) return BA_ERR_INVALID;
+  if (!h->has_problem) return fail(h, BA_ERR_STATE, "upload_guess before set_problem");
+  if (!poses || !points) return fail(h, BA_ERR_INVALID, "null poses/points");
+  HIP_TRY(h, hipSetDevice(h->device));
+  int rc = stage_state(h, poses, points, h->poses_init, h->pts_init);
+  if (rc) return rc;
+  h->has_guess = true;
+  h->has_estimate = false;
+  return BA_OK;
+}
+
+int ba_solve_resident(ba_handle* h, ba_report* report) {
+  if (!h) return BA_ERR_INVALID;
+  if (!h->has_guess) return fail(h, BA_ERR_STATE, "solve before upload_guess");
+  ba_report local;
+  HIP_TRY(h, hipSetDevice(h->device));
+  return lm_solve(h, report ? report : &local);
+}
+
+int ba_download_estimate(ba_handle* h, double* poses, double* points) {
+  if (!h) return BA_ERR_INVALID;
+  if (!h->has_estimate) return fail(h, BA_ERR_STATE, "download before a successful solve");
+  if (!poses || !points) return fail(h, BA_ERR_INVALID, "null poses/points");
+  HIP_TRY(h, hipSetDevice(h->device));
+  return fetch_state(h, h->poses_cur, h->pts_cur, poses, points);
+}
+
+int ba_solve(ba_handle* h, double* poses, double* points, ba_report* report) {
+  int rc = ba_upload_guess(h, poses, points);
+  if (rc) return rc;
+  if ((rc = ba_solve_resident(h, report))) return rc;
+  return ba_download_estimate(h, poses, points);
+}
+
+int ba_evaluate(ba_handle* h, const double* poses, const double* points, double* residuals, double* cost,
+                int32_t* n_behind) {
+  if (!h) return BA_ERR_INVALID;
+  if (!h->has_problem) return fail(h, BA_ERR_STATE, "evaluate before set_problem");
+  if (!poses || !points) return fail(h, BA_ERR_INVALID, "null poses/points");
+  HIP_TRY(h, hipSetDevice(h->device));
+  int rc = stage_state(h, poses, points, h->poses_trial, h->pts_trial);
+  if (rc) return rc;
+  h->has_estimate = false;  // the trial buffers were clobbered
+  double* d_res = nullptr;
+  if (residuals) HIP_TRY(h, hipMalloc((void**)&d_res, (size_t)2 * h->n * sizeof(double)));
+  HIP_TRY(h, hipMemsetAsync(h->d.scal, 0, SC_COUNT * sizeof(double), h->stream));
+  launch_cost(h, h->poses_trial, h->pts_trial, SC_COST_T, SC_NBEHIND_T, d_res);
+  HIP_TRY(h, hipMemcpyAsync(h->scal_host, h->d.scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (residuals)
+    HIP_TRY(h, hipMemcpyAsync(residuals, d_res, (size_t)2 * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (d_res) (void)hipFree(d_res);
+  if (cost) *cost = h->scal_host[SC_COST_T];
+  if (n_behind) *n_behind = (int32_t)h->scal_host[SC_NBEHIND_T];
+  if (h->scal_host[SC_ZEROZ] > 0.0)
+    return fail(h, BA_ERR_NUMERICAL, "cannot project points with zero Z coordinates (division by zero)");
+  return BA_OK;
+}
+
+int ba_jacobian_blocks(ba_handle* h, const double* poses, const double* points, double* Jc, double* Jp) {
+  if (!h) return BA_ERR_INVALID;
+  if (!h->has_problem) return fail(h, BA_ERR_STATE, "jacobian_blocks before set_problem");
+  if (!poses || !points || !Jc || !Jp) return fail(h, BA_ERR_INVALID, "null argument");
+  HIP_TRY(h, hipSetDevice(h->device));
+  int rc = stage_state(h, poses, points, h->poses_trial, h->pts_trial);
+  if (rc) return rc;
+  h->has_estimate = false;
+  double *dJc = nullptr, *dJp = nullptr;
+  HIP_TRY(h, hipMalloc((void**)&dJc, (size_t)12 * h->n * sizeof(double)));
+  HIP_TRY(h, hipMalloc((void**)&dJp, (size_t)6 * h->n * sizeof(double)));
+  k_export_jac<<<std::min(grid_for(h->n), 4096), 256, 0, h->stream>>>(h->d, h->poses_trial, h->pts_trial, dJc, dJp);
+  HIP_TRY(h, hipMemcpyAsync(Jc, dJc, (size_t)12 * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(Jp, dJp, (size_t)6 * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  (void)hipFree(dJc);
+  (void)hipFree(dJp);
+  return BA_OK;
+}
+
+int ba_debug_linearization(ba_handle* h, const double* poses, const double* points, double lambda, double* U,
+                           double* V, double* W, double* gc, double* gp, double* S, double* rhs, double* dc,
+                           double* dp) {
+  if (!h) return BA_ERR_INVALID;
+  if (!h->has_problem) return fail(h, BA_ERR_STATE, "debug_linearization before set_problem");
+  if (!poses || !points) return fail(h, BA_ERR_INVALID, "null poses/points");
+  HIP_TRY(h, hipSetDevice(h->device));
+  int rc = stage_state(h, poses, points, h->poses_cur, h->pts_cur);
+  if (rc) return rc;
+  h->has_estimate = false;
+  const DeviceProblem& d = h->d;
+  const int C = h->C, Cf = h->Cf, L = h->L, n = h->n;
+  if ((rc = do_linearize(h, h->poses_cur, h->pts_cur))) return rc;
+  int pcg_it = 0;
+  if ((rc = do_reduced_solve(h, lambda, &pcg_it))) return rc;
+  HIP_TRY(h, hipMemcpyAsync(h->pts_trial, h->pts_cur, (size_t)3 * L * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  if ((rc = do_trial(h, lambda, h->poses_cur, h->pts_cur, h->poses_trial, h->pts_trial))) return rc;
+  auto fetch = [&](std::vector<double>& dst, const double* src, size_t count) -> int {
+    dst.resize(count);
+    HIP_TRY(h, hipMemcpy(dst.data(), src, count * sizeof(double), hipMemcpyDeviceToHost));
+    return BA_OK;
+  };
+  std::vector<double> t;
+  if (U || gc) {
+    if ((rc = fetch(t, d.Ugc, (size_t)27 * C))) return rc;
+    for (int c = 0; c < C; ++c) {
+      if (U)
+        for (int i = 0; i < 6; ++i)
+          for (int j = 0; j < 6; ++j)
+            U[36 * (size_t)c + 6 * i + j] = t[27 * (size_t)c + (i <= j ? sym6_index(i, j) : sym6_index(j, i))];
+      if (gc)
+        for (int i = 0; i < 6; ++i) gc[6 * (size_t)c + i] = t[27 * (size_t)c + 21 + i];
+    }
+  }
+  if (V) {
+    if ((rc = fetch(t, d.V, (size_t)6 * L))) return rc;
+    static const int m[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
+    for (int j = 0; j < L; ++j)
+      for (int e = 0; e < 9; ++e)
+        V[9 * (size_t)h->lm_internal_to_user[j] + e] = j < h->L_obs ? t[(size_t)m[e] * L + j] : 0.0;
+  }
+  if (gp) {
+    if ((rc = fetch(t, d.gp, (size_t)3 * L))) return rc;
+    for (int j = 0; j < L; ++j)
+      for (int e = 0; e < 3; ++e) gp[3 * (size_t)h->lm_internal_to_user[j] + e] = j < h->L_obs ? t[(size_t)e * L + j] : 0.0;
+  }
+  if (W) {
+    if ((rc = fetch(t, d.W, (size_t)18 * n))) return rc;
+    for (int k = 0; k < n; ++k)
+      for (int e = 0; e < 18; ++e) W[18 * (size_t)h->obs_src[k] + e] = t[(size_t)e * n + k];
+  }
+  if (S) {
+    std::vector<int> urow, low_of;
+    if ((rc = fetch(t, d.S, (size_t)36 * (d.nu + d.nl)))) return rc;
+    const size_t N = (size_t)6 * C;
+    std::fill(S, S + N * N, 0.0);
+    for (int c = 0; c < C; ++c)
+      if (h->fixed[c])
+        for (int i = 0; i < 6; ++i) S[((size_t)6 * c + i) * N + 6 * c + i] = 1.0;
+    for (int f = 0; f < Cf; ++f)
+      for (int s = h->urow_ptr[f]; s < h->urow_ptr[f + 1]; ++s) {
+        const int ci = h->free2cam[f], cj = h->free2cam[h->ucol[s]];
+        for (int i = 0; i < 6; ++i)
+          for (int j = 0; j < 6; ++j) {
+            const double v = t[36 * (size_t)s + 6 * i + j];
+            S[((size_t)6 * ci + i) * N + 6 * cj + j] = v;
+            S[((size_t)6 * cj + j) * N + 6 * ci + i] = v;
+          }
+      }
+  }
+  if (rhs) {
+    if ((rc = fetch(t, d.rhs, (size_t)6 * Cf))) return rc;
+    std::fill(rhs, rhs + (size_t)6 * C, 0.0);
+    for (int f = 0; f < Cf; ++f)
+      for (int i = 0; i < 6; ++i) rhs[6 * (size_t)h->free2cam[f] + i] = t[6 * (size_t)f + i];
+  }
+  if (dc) {
+    if ((rc = fetch(t, d.dc, (size_t)6 * Cf))) return rc;
+    std::fill(dc, dc + (size_t)6 * C, 0.0);
+    for (int f = 0; f < Cf; ++f)
+      for (int i = 0; i < 6; ++i) dc[6 * (size_t)h->free2cam[f] + i] = t[6 * (size_t)f + i];
+  }
+  if (dp) {
+    std::vector<double> a, b;
+    if ((rc = fetch(a, h->pts_trial, (size_t)3 * L)) || (rc = fetch(b, h->pts_cur, (size_t)3 * L))) return rc;
+    for (int j = 0; j < L; ++j)
+      for (int e = 0; e < 3; ++e)
+        dp[3 * (size_t)h->lm_internal_to_user[j] + e] = j < h->L_obs ? a[3 * (size_t)j + e] - b[3 * (size_t)j + e] : 0.0;
+  }
+  return BA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,224 @@
+"""ctypes binding of libba_amd.so (include/ba_amd.h) -- the thin shim between the Python entry
+point and the HIP kernels.  There is no CPU fallback: if the library or a GPU is missing, every call
+raises (the product path must fail loudly rather than silently compute elsewhere)."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .validation_error import ProcessingError, ValidationError
+
+BA_HISTORY = 128
+_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib", "libba_amd.so")
+
+STATUS_NAMES = {0: "max_iters", 1: "gtol", 2: "ftol", 3: "xtol"}
+
+
+class BaOptions(C.Structure):
+    _fields_ = [
+        ("max_iters", C.c_int32), ("ftol", C.c_double), ("xtol", C.c_double), ("gtol", C.c_double),
+        ("lambda0", C.c_double), ("lambda_min", C.c_double), ("lambda_max", C.c_double),
+        ("min_diag", C.c_double), ("accept_ratio", C.c_double), ("guard_cheirality", C.c_int32),
+        ("linear_solver", C.c_int32), ("pcg_tol", C.c_double), ("pcg_max_iter", C.c_int32),
+        ("pcg_check_every", C.c_int32), ("device", C.c_int32), ("verbose", C.c_int32),
+    ]
+
+
+class BaReport(C.Structure):
+    _fields_ = [
+        ("cost0", C.c_double), ("cost", C.c_double), ("grad_inf", C.c_double), ("lambda_", C.c_double),
+        ("rms_reproj", C.c_double), ("iterations", C.c_int32), ("accepted", C.c_int32),
+        ("linearizations", C.c_int32), ("status", C.c_int32), ("pcg_iters", C.c_int32), ("nobs", C.c_int32),
+        ("solve_ms", C.c_double), ("setup_ms", C.c_double), ("n_history", C.c_int32),
+        ("cost_history", C.c_double * BA_HISTORY), ("lambda_history", C.c_double * BA_HISTORY),
+        ("pcg_history", C.c_int32 * BA_HISTORY), ("accepted_history", C.c_int32 * BA_HISTORY),
+    ]
+
+    def as_dict(self) -> dict:
+        n = self.n_history
+        return dict(cost0=self.cost0, cost=self.cost, grad_inf=self.grad_inf, lam=self.lambda_,
+                    rms_reproj=self.rms_reproj, iterations=self.iterations, accepted=self.accepted,
+                    linearizations=self.linearizations, status=self.status,
+                    status_name=STATUS_NAMES.get(self.status, "?"), pcg_iters=self.pcg_iters, nobs=self.nobs,
+                    solve_ms=self.solve_ms, setup_ms=self.setup_ms, cost_history=list(self.cost_history[:n]),
+                    lambda_history=list(self.lambda_history[:n]), pcg_history=list(self.pcg_history[:n]),
+                    accepted_history=list(self.accepted_history[:n]))
+
+
+_lib = None
+
+_P = C.c_void_p
+_D = C.POINTER(C.c_double)
+_I = C.POINTER(C.c_int32)
+_SIGNATURES = {
+    "ba_version": (C.c_int, []),
+    "ba_device_count": (C.c_int, []),
+    "ba_default_options": (None, [C.POINTER(BaOptions)]),
+    "ba_create": (C.c_int, [C.POINTER(BaOptions), C.POINTER(_P)]),
+    "ba_destroy": (None, [_P]),
+    "ba_last_error": (C.c_char_p, [_P]),
+    "ba_set_problem": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _I, _I, _D, _D, C.POINTER(C.c_uint8)]),
+    "ba_solve": (C.c_int, [_P, _D, _D, C.POINTER(BaReport)]),
+    "ba_upload_guess": (C.c_int, [_P, _D, _D]),
+    "ba_solve_resident": (C.c_int, [_P, C.POINTER(BaReport)]),
+    "ba_download_estimate": (C.c_int, [_P, _D, _D]),
+    "ba_evaluate": (C.c_int, [_P, _D, _D, _D, _D, _I]),
+    "ba_jacobian_blocks": (C.c_int, [_P, _D, _D, _D, _D]),
+    "ba_debug_linearization": (C.c_int, [_P, _D, _D, C.c_double] + [_D] * 9),
+    "ba_schur_block_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load_library():
+    """Load libba_amd.so (does not touch the GPU).  Raises RuntimeError if it was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} not found: build it with `make -C visual-odometry_amd/csrc` "
+                               "(or __graft_entry__.build()); there is no CPU fallback")
+        lib = C.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _dptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(_D)
+
+
+def _f64(a, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != shape:
+        raise ValidationError(f"expected array of shape {shape}, got {a.shape}")
+    return a
+
+
+class Solver:
+    """One GPU-resident BA problem (wraps a ba_handle).  Use as a context manager or call close()."""
+
+    def __init__(self, **options):
+        lib = load_library()
+        self._lib = lib
+        self.opt = BaOptions()
+        lib.ba_default_options(C.byref(self.opt))
+        for k, v in options.items():
+            if not hasattr(self.opt, k):
+                raise ValidationError(f"unknown solver option {k!r}")
+            setattr(self.opt, k, v)
+        self._h = _P()
+        rc = lib.ba_create(C.byref(self.opt), C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise RuntimeError(f"ba_create failed with status {rc}: no usable MI355X / HIP device "
+                               "(the solver has no CPU fallback)")
+        self.C = self.L = self.n = 0
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ba_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc == 0:
+            return
+        msg = self._lib.ba_last_error(self._h).decode("utf-8", "replace")
+        if rc == 1:
+            raise ValidationError(msg)
+        if rc == 2:
+            raise ProcessingError(msg)
+        raise RuntimeError(f"libba_amd status {rc}: {msg}")
+
+    # -- problem
+    def set_problem(self, n_cams, n_pts, obs_cam, obs_pt, obs_uv, intr, fixed=None):
+        obs_cam = np.ascontiguousarray(obs_cam, dtype=np.int32)
+        obs_pt = np.ascontiguousarray(obs_pt, dtype=np.int32)
+        n = len(obs_cam)
+        if obs_pt.shape != (n,):
+            raise ValidationError("obs_cam and obs_pt must have the same length")
+        obs_uv = _f64(obs_uv, (n, 2))
+        intr = _f64(intr, (7,))
+        fx = None
+        if fixed is not None:
+            fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
+            if fixed.shape != (n_cams,):
+                raise ValidationError("fixed mask must have one entry per camera")
+            fx = fixed.ctypes.data_as(C.POINTER(C.c_uint8))
+        self._check(self._lib.ba_set_problem(self._h, n_cams, n_pts, n, obs_cam.ctypes.data_as(_I),
+                                             obs_pt.ctypes.data_as(_I), _dptr(obs_uv), _dptr(intr), fx))
+        self.C, self.L, self.n = int(n_cams), int(n_pts), int(n)
+
+    def _state(self, poses, points):
+        return _f64(poses, (self.C, 7)).copy(), _f64(points, (self.L, 3)).copy()
+
+    def solve(self, poses, points):
+        poses, points = self._state(poses, points)
+        rep = BaReport()
+        self._check(self._lib.ba_solve(self._h, _dptr(poses), _dptr(points), C.byref(rep)))
+        return poses, points, rep.as_dict()
+
+    def upload_guess(self, poses, points):
+        poses, points = self._state(poses, points)
+        self._check(self._lib.ba_upload_guess(self._h, _dptr(poses), _dptr(points)))
+
+    def solve_resident(self) -> dict:
+        rep = BaReport()
+        self._check(self._lib.ba_solve_resident(self._h, C.byref(rep)))
+        return rep.as_dict()
+
+    def download_estimate(self, poses, points):
+        poses, points = self._state(poses, points)
+        self._check(self._lib.ba_download_estimate(self._h, _dptr(poses), _dptr(points)))
+        return poses, points
+
+    def evaluate(self, poses, points, want_residuals=True):
+        poses, points = self._state(poses, points)
+        res = np.empty(2 * self.n) if want_residuals else None
+        cost = C.c_double()
+        nb = C.c_int32()
+        self._check(self._lib.ba_evaluate(self._h, _dptr(poses), _dptr(points), _dptr(res), C.byref(cost),
+                                          C.byref(nb)))
+        return res, cost.value, nb.value
+
+    def jacobian_blocks(self, poses, points):
+        poses, points = self._state(poses, points)
+        Jc = np.empty((self.n, 2, 6))
+        Jp = np.empty((self.n, 2, 3))
+        self._check(self._lib.ba_jacobian_blocks(self._h, _dptr(poses), _dptr(points), _dptr(Jc), _dptr(Jp)))
+        return Jc, Jp
+
+    def debug_linearization(self, poses, points, lam, want_S=True):
+        poses, points = self._state(poses, points)
+        Cn, L, n = self.C, self.L, self.n
+        out = dict(U=np.empty((Cn, 6, 6)), V=np.empty((L, 3, 3)), W=np.empty((n, 6, 3)), gc=np.empty((Cn, 6)),
+                   gp=np.empty((L, 3)), S=np.empty((6 * Cn, 6 * Cn)) if want_S else None, rhs=np.empty(6 * Cn),
+                   dc=np.empty((Cn, 6)), dp=np.empty((L, 3)))
+        self._check(self._lib.ba_debug_linearization(
+            self._h, _dptr(poses), _dptr(points), float(lam), *[_dptr(out[k]) for k in
+                                                                ("U", "V", "W", "gc", "gp", "S", "rhs", "dc", "dp")]))
+        return out
+
+    def schur_block_count(self) -> int:
+        v = C.c_int64()
+        self._check(self._lib.ba_schur_block_count(self._h, C.byref(v)))
+        return v.value

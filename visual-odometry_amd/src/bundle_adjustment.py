@@ -1,0 +1,148 @@
+"""BundleAdjustment -- drop-in for reference ``src/bundle_adjustment.py``.
+
+Same class, method names, argument order and return triple as the reference
+(bundle_adjustment.py:12-27, 89-92, 156-163, 288); the optimisation itself runs on an MI355X
+through libba_amd.so (hand-written HIP kernels: analytic Jacobians, U/V/W block assembly, Schur
+complement, block-Jacobi PCG, back-substitution, Levenberg-Marquardt) instead of
+``scipy.optimize.least_squares`` with a ``jac_sparsity`` mask (:201-219).
+
+Deliberate differences from the reference:
+* observations are paired with landmarks *by id* (the reference pairs id-sorted projections with
+  stored-order observations, which is only right for ascending ids);
+* images may hold different numbers of observations (the reference's ``np.array(residuals)``
+  needs equal counts, :86); landmarks nobody observes are returned untouched;
+* ``bundle_adjustment_sparsity`` returns the mask without printing it densely (:153).
+"""
+
+from typing import List, Optional, Tuple
+
+import numpy as np
+from scipy.sparse import coo_matrix, lil_matrix
+
+from . import _native
+from .camera import PinHoleCamera
+from .camera_pose import CameraPose
+from .feature_observation import Features2D, ImageFeatures, Landmarks3D
+from .validation_error import ValidationError
+
+
+def _pack_observations(observations: List[ImageFeatures], landmark_ids: np.ndarray):
+    """Flatten a list of ImageFeatures into (obs_cam, obs_pt, obs_uv), image-major, stored order.
+    obs_pt holds the landmark *index* in ``landmark_ids`` (ids are matched explicitly)."""
+    landmark_ids = np.asarray(landmark_ids)
+    order = np.argsort(landmark_ids, kind="stable")
+    sorted_ids = landmark_ids[order]
+    if len(sorted_ids) > 1 and np.any(sorted_ids[1:] == sorted_ids[:-1]):
+        raise ValidationError("landmark ids must be unique")
+    cams, pts, uvs = [], [], []
+    for i, feats in enumerate(observations):
+        f2d = feats.get_points_2d()
+        ids = f2d.get_ids()
+        if len(ids) == 0:
+            continue
+        pos = np.searchsorted(sorted_ids, ids)
+        pos = np.clip(pos, 0, len(sorted_ids) - 1)
+        if np.any(sorted_ids[pos] != ids):
+            missing = ids[sorted_ids[pos] != ids][0]
+            raise ValidationError(f"image {i} observes landmark id {missing} that is not in points3d_guess")
+        cams.append(np.full(len(ids), i, dtype=np.int32))
+        pts.append(order[pos].astype(np.int32))
+        uvs.append(f2d.get_points_2d())
+    if not cams:
+        raise ValidationError("no observations")
+    return np.concatenate(cams), np.concatenate(pts), np.vstack(uvs)
+
+
+def _pose_rows(camera_pose_initial: CameraPose, poses: List[CameraPose]) -> np.ndarray:
+    return np.array([np.concatenate([p.position, p.quaternion]) for p in [camera_pose_initial] + list(poses)])
+
+
+class BundleAdjustment:
+    """Bundle adjustment of 3-D landmarks and camera poses (first pose fixed)."""
+
+    def __init__(self, **solver_options) -> None:
+        # the reference constructor takes nothing (bundle_adjustment.py:15-16); options are an extension
+        self.solver_options = solver_options
+        self.last_report: Optional[dict] = None
+
+    # ------------------------------------------------------------------ residuals (reference :19-87)
+    @staticmethod
+    def residual_function(params: np.ndarray, camera_pose_initial: CameraPose, num_poses: int,
+                          landmark_ids: np.ndarray, observations: List[ImageFeatures],
+                          camera_model: PinHoleCamera) -> np.ndarray:
+        """Residuals [u0-u0', v0-v0', ...] of parameter vector [7*num_poses poses | 3*L landmarks],
+        image-major, evaluated by the HIP residual kernel."""
+        params = np.asarray(params, dtype=np.float64)
+        L = len(landmark_ids)
+        if params.shape != (7 * num_poses + 3 * L,):
+            raise ValidationError(f"params must have {7 * num_poses + 3 * L} entries, got {params.shape}")
+        if len(observations) != num_poses + 1:
+            raise ValidationError("observations must hold num_poses + 1 images")
+        obs_cam, obs_pt, obs_uv = _pack_observations(observations, landmark_ids)
+        poses = np.vstack([np.concatenate([camera_pose_initial.position, camera_pose_initial.quaternion])[None],
+                           params[: 7 * num_poses].reshape(num_poses, 7)])
+        with _native.Solver() as s:
+            s.set_problem(num_poses + 1, L, obs_cam, obs_pt, obs_uv, camera_model.to_vector())
+            res, _, _ = s.evaluate(poses, params[7 * num_poses:].reshape(L, 3))
+        return res
+
+    # ------------------------------------------------------------------ mask (reference :89-154)
+    @staticmethod
+    def bundle_adjustment_sparsity(num_poses: int, num_landmarks: int,
+                                   observations: List[ImageFeatures]) -> lil_matrix:
+        """0/1 Jacobian pattern in the reference's 7-parameter layout.  Kept for API parity; the
+        GPU solver does not use it (its pattern is the observation index itself)."""
+        ids = np.unique(np.concatenate([o.get_points_2d().get_ids() for o in observations]))
+        obs_cam, obs_pt, _ = _pack_observations(observations, ids)  # rank among observed ids (:118-123)
+        nobs = len(obs_cam)
+        rows2 = np.arange(2 * nobs)
+        k = rows2 // 2
+        r = [np.repeat(rows2, 3)]
+        c = [((num_poses * 7 + 3 * obs_pt[k])[:, None] + np.arange(3)[None, :]).reshape(-1)]
+        free = obs_cam[k] > 0
+        r.append(np.repeat(rows2[free], 7))
+        c.append((((obs_cam[k][free] - 1) * 7)[:, None] + np.arange(7)[None, :]).reshape(-1))
+        r, c = np.concatenate(r), np.concatenate(c)
+        return coo_matrix((np.ones(len(r), dtype=int), (r, c)),
+                          shape=(2 * nobs, num_poses * 7 + num_landmarks * 3)).tolil()
+
+    # ------------------------------------------------------------------ optimise (reference :156-288)
+    def optimize(self, image_features_list: List[ImageFeatures], camera_pose_initial: CameraPose,
+                 camera_model: PinHoleCamera, camera_poses_guess: List[CameraPose],
+                 points3d_guess: Landmarks3D) -> Tuple[List[ImageFeatures], Landmarks3D, List[CameraPose]]:
+        if len(image_features_list) != len(camera_poses_guess) + 1:
+            raise ValidationError("image_features_list must hold len(camera_poses_guess) + 1 images")
+        landmark_ids = points3d_guess.get_ids()
+        points0 = points3d_guess.get_points_3d()
+        obs_cam, obs_pt, obs_uv = _pack_observations(image_features_list, landmark_ids)
+        poses0 = _pose_rows(camera_pose_initial, camera_poses_guess)
+        n_cams = len(image_features_list)
+
+        with _native.Solver(**self.solver_options) as solver:
+            solver.set_problem(n_cams, len(landmark_ids), obs_cam, obs_pt, obs_uv, camera_model.to_vector())
+            poses, points, report = solver.solve(poses0, points0)
+        self.last_report = report
+
+        # unpack (reference :221-244): fixed pose first, original timestamps, unit quaternions
+        optimized_camera_poses = [camera_pose_initial]
+        for i, guess in enumerate(camera_poses_guess):
+            row = poses[i + 1]
+            optimized_camera_poses.append(CameraPose(row[:3].copy(), row[3:7] / np.linalg.norm(row[3:7]),
+                                                     guess.timestamp))
+        optimized_points3d = Landmarks3D(points, landmark_ids)
+
+        # re-project the observed landmarks through the optimised poses (reference :246-286);
+        # width/height come from image 0 (:190-191)
+        image_width = image_features_list[0].image_width
+        image_height = image_features_list[0].image_height
+        optimized_image_features = []
+        for i, feats in enumerate(image_features_list):
+            sel = obs_cam == i
+            if not np.any(sel):
+                optimized_image_features.append(feats)
+                continue
+            pts_cam = optimized_camera_poses[i].transform_points_world_to_camera(points[obs_pt[sel]])
+            optimized_image_features.append(
+                ImageFeatures(feats.get_timestamp(), feats.get_camera_id(), image_width, image_height,
+                              Features2D(camera_model.project(pts_cam), feats.get_points_2d().get_ids())))
+        return optimized_image_features, optimized_points3d, optimized_camera_poses
