@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- observations/sec per LM iteration + time-to-converge of the MI355X BA solver.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|small]
+
+A "step" is one complete solve (ba_solve_resident) of the synthetic ring scene from the same initial
+guess, with observations, poses and points already resident in HBM; value = observations x LM
+iterations summed over the K timed steps / wall time of those steps (max over ranks).  N = 1 runs
+BASELINE.json configs[1] (50 cameras x 20k landmarks x 200k observations).  For N > 1 (launched by
+torch.distributed.run, one rank per GPU) every rank solves its own replica-sized shard: see
+DESIGN.md "Multi-GPU".  Rank 0 prints ONE JSON line.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "visual-odometry_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+WORKLOADS = {  # name -> (cameras, landmarks, track length)       
+    "small": (50, 2000, 10),
+    "cfg2": (50, 20000, 10),
+    "cfg3": (1000, 200000, 5),
+    "cfg4": (10000, 2000000, 5),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes(kernel: str, nobs: int, n_lm: int, n_cam: int) -> float:
+    """Bytes one launch must move (DESIGN.md 'Kernels'; SURVEY.md section 8d per-unit figures)."""
+    if kernel == "k_linearize":  # read cam idx + u + v, write W; per landmark read P, write V + gp; U/gc per camera
+        return 168.0 * nobs + 120.0 * n_lm + 392.0 * n_cam
+    if kernel == "k_schur":  # read W + cam idx; per landmark V + gp; S written once
+        return 148.0 * nobs + 96.0 * n_lm
+    if kernel == "k_backsub":  # read W + cam idx; per landmark V, gp, P read, P written
+        return 148.0 * nobs + 144.0 * n_lm
+    if kernel == "k_cost":
+        return 24.0 * nobs + 24.0 * n_lm
+    raise KeyError(kernel)
+
+
+def cpu_baseline(scene, budget_s: float):
+    """The oracle's restatement of the reference path (scipy TRF + LSMR + sparse FD), 1 core."""
+    from oracle import ref_scipy_path as orc
+    n_poses = int(scene["num_poses"])
+    nobs = len(scene["obs_cam"])
+    t0 = time.perf_counter()
+    res, t_lsq, t_mask = orc.solve_scipy_path(scene["x0"], scene["pose0"], n_poses, scene["obs_cam"],
+                                              scene["obs_pt"], scene["obs_uv"], scene["intr"])
+    wall = time.perf_counter() - t0
+    return {
+        "value": nobs * res.nfev / wall, "unit": "observations*iterations/s", "cores": 1, "kind": "port",
+        "sample": f"full solve of the same scene by oracle/ref_scipy_path.solve_scipy_path "
+                  f"(scipy {__import__('scipy').__version__} least_squares trf+lsmr, jac_sparsity, tolerances 1e-6): "
+                  f"{res.nfev} nfev in {wall:.1f} s, status {res.status}",
+        "seconds": wall, "cost": float(res.cost), "nfev": int(res.nfev), "status": int(res.status),
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import scenes
+    from src import _native
+
+    C, L, d = WORKLOADS[args.workload]
+    scene = scenes.ring_scene(C, L, d, seed=rank)  # weak scaling: one replica-sized scene per rank
+    nobs = len(scene["obs_cam"])
+
+    solver = _native.Solver(device=local_rank, profile_kernels=0 if args.no_kernel_events else 1)
+    solver.set_problem(C, L, scene["obs_cam"], scene["obs_pt"], scene["obs_uv"], scene["intr"])
+    solver.upload_guess(scene["poses_guess"], scene["points_guess"])
+
+    def barrier():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        rep = solver.solve_resident()
+    k0 = solver.kernel_times()
+    barrier()
+    t0 = time.perf_counter()
+    iters = 0
+    for _ in range(args.steps):
+        rep = solver.solve_resident()  # synchronous: returns after the stream is idle
+        iters += rep["iterations"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    k1 = solver.kernel_times()
+
+    units = float(nobs) * iters
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        u = torch.tensor([units], dtype=torch.float64, device="cuda")
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        units = float(u.item())
+
+    if rank == 0:
+        ktimes = {k: ((k1[k][0] - k0[k][0]), (k1[k][1] - k0[k][1])) for k in k1}
+        big = {k: v for k, v in ktimes.items() if k in ("k_linearize", "k_schur", "k_backsub", "k_cost") and v[1] > 0}
+        roofline = None
+        if big:
+            dom = max(big, key=lambda k: big[k][0])
+            avg_ms = big[dom][0] / big[dom][1]
+            bytes_launch = algorithmic_bytes(dom, nobs, L, C)
+            ach = bytes_launch / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": avg_ms,
+                        "algorithmic_bytes_per_launch": bytes_launch,
+                        "per_kernel": {k: {"total_ms": v[0], "launches": v[1],
+                                           "avg_us": 1e3 * v[0] / max(v[1], 1),
+                                           "GBps": (algorithmic_bytes(k, nobs, L, C) / (v[0] / v[1] * 1e-3) / 1e9)
+                                           if k in big else None}
+                                       for k, v in ktimes.items()}}
+        out = {
+            "metric": "observations/sec per LM iteration", "value": units / elapsed,
+            "unit": "observations*iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: ring scene {C} cameras x {L} landmarks x {nobs} observations "
+                                   f"(track length {d}), sigma_px 0.5, per GPU",
+                       "cameras": C, "landmarks": L, "observations": nobs, "parallelism": f"replica x{world}"},
+            "time_to_converge_ms": rep["solve_ms"], "lm_iterations": rep["iterations"],
+            "pcg_iterations": rep["pcg_iters"], "final_cost": rep["cost"], "status": rep["status_name"],
+            "rms_reproj_px": rep["rms_reproj"], "setup_ms": rep["setup_ms"],
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cb = cpu_baseline(scene, 30.0)
+            out["cpu_baseline"] = cb
+            out["cost_vs_cpu_baseline"] = rep["cost"] / cb["cost"] - 1.0
+        print(json.dumps(out))
+    solver.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -69,6 +69,7 @@ typedef struct {
   int32_t pcg_check_every;  /* PCG iterations between host polls of the device-side stop flag, 10 */
   int32_t device;           /* HIP device ordinal; -1 = current device */
   int32_t verbose;          /* 1 = print one line per LM iteration to stderr */
+  int32_t profile_kernels;  /* 1 = bracket every kernel class with HIP events (ba_get_kernel_times) */
 } ba_options;
 
 typedef struct {
@@ -158,6 +159,13 @@ int ba_jacobian_blocks(ba_handle* h, const double* poses, const double* points, 
 int ba_debug_linearization(ba_handle* h, const double* poses, const double* points, double lambda, double* U,
                            double* V, double* W, double* gc, double* gp, double* S, double* rhs, double* dc,
                            double* dp);
+
+/* Device time per kernel class, measured with HIP events on the solver's own stream during the
+ * solves since the last ba_set_problem (needs opt.profile_kernels = 1).  Classes:
+ * 0 k_linearize, 1 k_schur, 2 k_backsub, 3 k_cost, 4 PCG (all its launches), 5 k_schur_init +
+ * k_damp_mirror + k_pose_update + memsets.  No reference counterpart (bench.py's roofline figures). */
+#define BA_KERNEL_CLASSES 6
+int ba_get_kernel_times(ba_handle* h, double* total_ms, int32_t* launches);
 
 /* Number of stored 6x6 blocks of the reduced camera system (upper triangle incl. diagonal). */
 int ba_schur_block_count(const ba_handle* h, int64_t* n_upper_blocks);

@@ -214,5 +214,9 @@ def test_error_mapping(golden):
         # a landmark exactly on camera 0's principal plane: z == 0 -> ProcessingError (camera.py:129-132)
         flat = pts.copy()
         flat[3, 2] = 0.0
+        ident = poses.copy()
+        ident[0] = [0, 0, 0, 1, 0, 0, 0]
         with pytest.raises(ProcessingError):
-            s.evaluate(poses, flat)
+            s.evaluate(ident, flat)
+        with pytest.raises(ProcessingError):
+            s.solve(ident, flat)

@@ -53,6 +53,14 @@ struct ba_handle {
   double* scal_host = nullptr;  // pinned
   double* stage = nullptr;      // pinned staging for pose / point transfers
   size_t stage_bytes = 0;
+
+  // optional HIP-event timing per kernel class (opt.profile_kernels)
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  struct Span { int cls; hipEvent_t a, b; };
+  std::vector<Span> spans;
+  double ktime_ms[BA_KERNEL_CLASSES] = {0, 0, 0, 0, 0, 0};
+  int kcount[BA_KERNEL_CLASSES] = {0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -75,7 +83,47 @@ int fail(ba_handle* h, int code, const char* fmt, ...) {
                   #expr, hipGetErrorString(e_));                                                \
   } while (0)
 
+enum { KT_LIN = 0, KT_SCHUR, KT_BACKSUB, KT_COST, KT_PCG, KT_OTHER };
+
+hipEvent_t next_event(ba_handle* h) {
+  if (h->ev_used == h->ev_pool.size()) {
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    h->ev_pool.push_back(e);
+  }
+  return h->ev_pool[h->ev_used++];
+}
+
+// RAII bracket: records an event pair around the launches issued while it is alive.
+struct KSpan {
+  ba_handle* h;
+  int cls;
+  hipEvent_t a = nullptr;
+  KSpan(ba_handle* h_, int cls_, int launches = 1) : h(h_), cls(cls_) {
+    if (!h->opt.profile_kernels) return;
+    a = next_event(h);
+    (void)hipEventRecord(a, h->stream);
+    h->kcount[cls] += launches;
+  }
+  ~KSpan() {
+    if (!a) return;
+    hipEvent_t b = next_event(h);
+    (void)hipEventRecord(b, h->stream);
+    h->spans.push_back({cls, a, b});
+  }
+};
+
+void collect_spans(ba_handle* h) {  // call after the stream is idle
+  for (auto& s : h->spans) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) h->ktime_ms[s.cls] += ms;
+  }
+  h->spans.clear();
+  h->ev_used = 0;
+}
+
 void free_problem(ba_handle* h) {
+  for (int i = 0; i < BA_KERNEL_CLASSES; ++i) { h->ktime_ms[i] = 0.0; h->kcount[i] = 0; }
   for (void* p : h->allocs) (void)hipFree(p);
   h->allocs.clear();
   if (h->stage) (void)hipHostFree(h->stage);
@@ -170,7 +218,10 @@ void launch_cost(ba_handle* h, const double* poses, const double* pts, int cost_
 int do_linearize(ba_handle* h, const double* poses, const double* pts) {
   HIP_TRY(h, hipMemsetAsync(h->d.scal, 0, SC_COUNT * sizeof(double), h->stream));
   HIP_TRY(h, hipMemsetAsync(h->d.Ugc, 0, (size_t)h->C * 27 * sizeof(double), h->stream));
-  launch_linearize(h, poses, pts);
+  {
+    KSpan t(h, KT_LIN);
+    launch_linearize(h, poses, pts);
+  }
   return BA_OK;
 }
 
@@ -178,21 +229,36 @@ int do_linearize(ba_handle* h, const double* poses, const double* pts) {
 int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
   DeviceProblem& d = h->d;
   const ba_options& o = h->opt;
-  HIP_TRY(h, hipMemsetAsync(d.S, 0, (size_t)(d.nu + d.nl) * 36 * sizeof(double), h->stream));
-  k_schur_init<<<grid_for(d.Cf), 256, 0, h->stream>>>(d);
-  launch_schur(h, lam);
-  k_damp_mirror<<<grid_for(d.nu), 256, 0, h->stream>>>(d, lam, o.min_diag);
+  {
+    KSpan t(h, KT_OTHER, 2);
+    HIP_TRY(h, hipMemsetAsync(d.S, 0, (size_t)(d.nu + d.nl) * 36 * sizeof(double), h->stream));
+    k_schur_init<<<grid_for(d.Cf), 256, 0, h->stream>>>(d);
+  }
+  {
+    KSpan t(h, KT_SCHUR);
+    launch_schur(h, lam);
+  }
+  {
+    KSpan t(h, KT_OTHER, 1);
+    k_damp_mirror<<<grid_for(d.nu), 256, 0, h->stream>>>(d, lam, o.min_diag);
+  }
   const int gv = grid_for(6L * d.Cf);
-  k_pcg_init<<<gv, 256, 0, h->stream>>>(d);
+  {
+    KSpan t(h, KT_PCG, 1);
+    k_pcg_init<<<gv, 256, 0, h->stream>>>(d);
+  }
   const double tol2 = o.pcg_tol * o.pcg_tol;
   const int every = std::max(1, o.pcg_check_every);
   int launched = 0;
   while (launched < o.pcg_max_iter) {
     const int nb = std::min(every, o.pcg_max_iter - launched);
-    for (int i = 0; i < nb; ++i) {
-      k_pcg_spmv<<<gv, 256, 0, h->stream>>>(d);
-      k_pcg_update<<<gv, 256, 0, h->stream>>>(d);
-      k_pcg_dir<<<gv, 256, 0, h->stream>>>(d, tol2, o.pcg_max_iter);
+    {
+      KSpan t(h, KT_PCG, 3 * nb);
+      for (int i = 0; i < nb; ++i) {
+        k_pcg_spmv<<<gv, 256, 0, h->stream>>>(d);
+        k_pcg_update<<<gv, 256, 0, h->stream>>>(d);
+        k_pcg_dir<<<gv, 256, 0, h->stream>>>(d, tol2, o.pcg_max_iter);
+      }
     }
     launched += nb;
     HIP_TRY(h, hipMemcpyAsync(h->scal_host + SC_RZ, d.scal + SC_RZ, 8 * sizeof(double), hipMemcpyDeviceToHost,
@@ -207,9 +273,18 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
 // step statistics + trial state + trial cost; leaves everything in scal
 int do_trial(ba_handle* h, double lam, const double* poses, const double* pts, double* poses_t, double* pts_t) {
   DeviceProblem& d = h->d;
-  k_pose_update<<<grid_for(d.C), 256, 0, h->stream>>>(d, poses, poses_t);
-  launch_backsub(h, lam, pts, pts_t);
-  launch_cost(h, poses_t, pts_t, SC_COST_T, SC_NBEHIND_T, nullptr);
+  {
+    KSpan t(h, KT_OTHER, 1);
+    k_pose_update<<<grid_for(d.C), 256, 0, h->stream>>>(d, poses, poses_t);
+  }
+  {
+    KSpan t(h, KT_BACKSUB);
+    launch_backsub(h, lam, pts, pts_t);
+  }
+  {
+    KSpan t(h, KT_COST);
+    launch_cost(h, poses_t, pts_t, SC_COST_T, SC_NBEHIND_T, nullptr);
+  }
   HIP_TRY(h, hipMemcpyAsync(h->scal_host, d.scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return BA_OK;
@@ -349,6 +424,7 @@ int lm_solve(ba_handle* h, ba_report* rep) {
   if (pts != h->pts_cur) std::swap(h->pts_cur, h->pts_trial);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   rep->solve_ms = ms_since(t0);
+  collect_spans(h);
   rep->cost = cost;
   rep->lambda = lam;
   rep->iterations = it;
@@ -389,6 +465,7 @@ void ba_default_options(ba_options* o) {
   o->pcg_check_every = 10;
   o->device = -1;
   o->verbose = 0;
+  o->profile_kernels = 0;
 }
 
 int ba_create(const ba_options* opt, ba_handle** out) {
@@ -420,11 +497,18 @@ void ba_destroy(ba_handle* h) {
   (void)hipSetDevice(h->device);
   free_problem(h);
   if (h->scal_host) (void)hipHostFree(h->scal_host);
+  for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
 
 const char* ba_last_error(const ba_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int ba_get_kernel_times(ba_handle* h, double* total_ms, int32_t* launches) {
+  if (!h || !total_ms || !launches) return BA_ERR_INVALID;
+  for (int i = 0; i < BA_KERNEL_CLASSES; ++i) { total_ms[i] = h->ktime_ms[i]; launches[i] = h->kcount[i]; }
+  return BA_OK;
+}
 
 int ba_schur_block_count(const ba_handle* h, int64_t* nu) {
   if (!h || !nu || !h->has_problem) return BA_ERR_STATE;

@@ -25,6 +25,7 @@ class BaOptions(C.Structure):
         ("min_diag", C.c_double), ("accept_ratio", C.c_double), ("guard_cheirality", C.c_int32),
         ("linear_solver", C.c_int32), ("pcg_tol", C.c_double), ("pcg_max_iter", C.c_int32),
         ("pcg_check_every", C.c_int32), ("device", C.c_int32), ("verbose", C.c_int32),
+        ("profile_kernels", C.c_int32),
     ]
 
 
@@ -70,6 +71,7 @@ _SIGNATURES = {
     "ba_jacobian_blocks": (C.c_int, [_P, _D, _D, _D, _D]),
     "ba_debug_linearization": (C.c_int, [_P, _D, _D, C.c_double] + [_D] * 9),
     "ba_schur_block_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "ba_get_kernel_times": (C.c_int, [_P, _D, _I]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -217,6 +219,14 @@ class Solver:
             self._h, _dptr(poses), _dptr(points), float(lam), *[_dptr(out[k]) for k in
                                                                 ("U", "V", "W", "gc", "gp", "S", "rhs", "dc", "dp")]))
         return out
+
+    KERNEL_CLASSES = ("k_linearize", "k_schur", "k_backsub", "k_cost", "pcg", "other")
+
+    def kernel_times(self) -> dict:
+        ms = np.zeros(6)
+        cnt = np.zeros(6, dtype=np.int32)
+        self._check(self._lib.ba_get_kernel_times(self._h, _dptr(ms), cnt.ctypes.data_as(_I)))
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KERNEL_CLASSES)}
 
     def schur_block_count(self) -> int:
         v = C.c_int64()
