@@ -42,6 +42,11 @@ struct DeviceProblem {
   // state
   double* W; double* V; double* gp; double* Ugc;
   double* S; double* rhs; double* Udiag; double* Minv;
+  // privatised accumulation slabs (atomics from different groups land in different copies; a reduce
+  // kernel sums the copies): Ugc_slab [nslab_u][C][27]; S_slab [nslab_s][nu*36 + 6*Cf] (S upper | rhs)
+  double* Ugc_slab; double* S_slab;
+  int nslab_u, nslab_s;
+  long s_slab_stride;
   double* dc; double* r; double* z; double* p; double* q;   // PCG vectors (dc is the solution x)
   double* scal;
 };
@@ -64,6 +69,7 @@ __global__ __launch_bounds__(256) void k_linearize(DeviceProblem d, const double
   const long j0 = group * lm_per_group;
   const long j1 = min((long)d.L_obs, j0 + lm_per_group);
   const long n = d.n;
+  double* __restrict__ Uslab = d.Ugc_slab + (long)(group % d.nslab_u) * d.C * 27;
   double acc[27];
 #pragma unroll
   for (int i = 0; i < 27; ++i) acc[i] = 0.0;
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(256) void k_linearize(DeviceProblem d, const double
           if (cam != cur_cam) {
             if (cur_cam >= 0) {
 #pragma unroll
-              for (int i = 0; i < 27; ++i) atomic_add_f64(&d.Ugc[(long)cur_cam * 27 + i], acc[i]);
+              for (int i = 0; i < 27; ++i) atomic_add_f64(&Uslab[(long)cur_cam * 27 + i], acc[i]);
             }
 #pragma unroll
             for (int i = 0; i < 27; ++i) acc[i] = 0.0;
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256) void k_linearize(DeviceProblem d, const double
   }
   if (cur_cam >= 0) {
 #pragma unroll
-    for (int i = 0; i < 27; ++i) atomic_add_f64(&d.Ugc[(long)cur_cam * 27 + i], acc[i]);
+    for (int i = 0; i < 27; ++i) atomic_add_f64(&Uslab[(long)cur_cam * 27 + i], acc[i]);
   }
   const double bc = block_sum_256(cost, red);
   const double bb = block_sum_256((double)nbehind, red);
@@ -202,28 +208,45 @@ __global__ __launch_bounds__(256) void k_export_jac(DeviceProblem d,
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_schur_init: S diagonal <- U (undamped), rhs <- gc, Udiag <- diag(U); gradient inf-norm of the
-// camera part.  One thread per free camera.  (S was zeroed by a memset node.)
-__global__ __launch_bounds__(256) void k_schur_init(DeviceProblem d) {
+// k_reduce_U: Ugc[c][e] = sum over slabs; inf-norm of the camera gradient.  One thread per entry.
+__global__ __launch_bounds__(256) void k_reduce_U(DeviceProblem d) {
   __shared__ double red[4];
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long tot = (long)d.C * 27;
   double gmax = 0.0;
-  if (f < d.Cf) {
-    const int cam = d.free2cam[f];
-    const double* u = d.Ugc + (long)cam * 27;
-    double* Sd = d.S + (long)d.diag_slot[f] * 36;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-#pragma unroll
-      for (int c = 0; c < 6; ++c) Sd[6 * i + c] = u[i <= c ? sym6_index(i, c) : sym6_index(c, i)];
-      d.Udiag[6 * f + i] = u[sym6_index(i, i)];
-      const double g = u[21 + i];
-      d.rhs[6 * f + i] = g;
-      gmax = fmax(gmax, fabs(g));
-    }
+  if (t < tot) {
+    double sum = 0.0;
+    for (int k = 0; k < d.nslab_u; ++k) sum += d.Ugc_slab[(long)k * tot + t];
+    d.Ugc[t] = sum;
+    const int cam = (int)(t / 27), e = (int)(t - 27L * cam);
+    if (e >= 21 && d.cam2free[cam] >= 0) gmax = fabs(sum);
   }
   const double bg = block_max_256(gmax, red);
   if (threadIdx.x == 0) atomic_max_nonneg(&d.scal[SC_GINF], bg);
+}
+
+// k_reduce_S: S (upper blocks) = sum of the slabs (+ U on the diagonal blocks), rhs = gc + sum of
+// the slabs' rhs part, Udiag = diag(U).  One thread per entry of [nu*36 | 6*Cf].
+__global__ __launch_bounds__(256) void k_reduce_S(DeviceProblem d) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nS = (long)d.nu * 36;
+  if (t >= nS + 6L * d.Cf) return;
+  double sum = 0.0;
+  for (int k = 0; k < d.nslab_s; ++k) sum += d.S_slab[(long)k * d.s_slab_stride + t];
+  if (t < nS) {
+    const int s = (int)(t / 36), e = (int)(t - 36L * s);
+    if (d.low_of[s] < 0) {
+      const int f = d.urow[s], i = e / 6, c = e - 6 * i;
+      const double u = d.Ugc[(long)d.free2cam[f] * 27 + (i <= c ? sym6_index(i, c) : sym6_index(c, i))];
+      sum += u;
+      if (i == c) d.Udiag[6 * f + i] = u;
+    }
+    d.S[t] = sum;
+  } else {
+    const long r = t - nS;
+    const int f = (int)(r / 6), i = (int)(r - 6L * f);
+    d.rhs[r] = sum + d.Ugc[(long)d.free2cam[f] * 27 + 21 + i];
+  }
 }
 
 // Find the upper-triangle slot of block (fa, fb), fa <= fb, by binary search in row fa.
@@ -260,10 +283,12 @@ __global__ __launch_bounds__(256) void k_schur(DeviceProblem d, double lam, doub
   int cur_a = -1, cur_b = -1;
   bool cur_sym = false;
   int nbad = 0;
+  double* __restrict__ Sslab = d.S_slab + (long)(group % d.nslab_s) * d.s_slab_stride;
+  double* __restrict__ Rslab = Sslab + (long)d.nu * 36;
 
   auto flush = [&]() {
     if (cur_a < 0) return;
-    double* Sb = d.S + (long)upper_slot(d, cur_a, cur_b) * 36;
+    double* Sb = Sslab + (long)upper_slot(d, cur_a, cur_b) * 36;
     if (cur_sym) {  // two observations of one landmark in the same image: add block + block^T
 #pragma unroll
       for (int i = 0; i < 6; ++i)
@@ -275,7 +300,7 @@ __global__ __launch_bounds__(256) void k_schur(DeviceProblem d, double lam, doub
     }
     if (cur_a == cur_b && !cur_sym) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) atomic_add_f64(&d.rhs[6 * cur_a + i], -accr[i]);
+      for (int i = 0; i < 6; ++i) atomic_add_f64(&Rslab[6 * cur_a + i], -accr[i]);
     }
 #pragma unroll
     for (int i = 0; i < 36; ++i) acc[i] = 0.0;
@@ -460,6 +485,165 @@ __global__ __launch_bounds__(256) void k_pcg_dir(DeviceProblem d, double tol2, i
     d.scal[SC_PQ] = 0.0;
     *reinterpret_cast<unsigned int*>(&d.scal[SC_COUNT - 1]) = 0u;
     if (!(rzn > tol2 * d.scal[SC_RZ0]) || !(pq > 0.0) || it >= (double)max_iter) d.scal[SC_DONE] = 1.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_solve_small: the whole reduced solve for a small camera system in ONE workgroup and ONE launch:
+// LM damping of the diagonal, block-Jacobi preconditioner, and the complete PCG loop with the
+// vectors in LDS.  With CACHED the upper blocks of S live in registers for the whole solve (each
+// thread owns up to ITEMS rows-of-a-block = 6 doubles each), so a PCG iteration touches no global
+// memory at all; otherwise S is streamed from L2 every iteration.  SpMV uses the symmetry:
+// q_i += B p_j and q_j += B^T p_i for every stored upper block B = S_ij (LDS fp64 atomics).
+// Bound: latency (barriers + LDS), not HBM: S is read once (288 B per block).
+constexpr int SMALL_THREADS = 1024;
+constexpr int SMALL_CACHED_ROWS = 4;
+
+__device__ __forceinline__ double block_sum_1024(double v, double* red /*[17]*/) {
+  v = group_sum<64>(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    double s = threadIdx.x < (SMALL_THREADS / 64) ? red[threadIdx.x] : 0.0;
+    s = group_sum<64>(s);
+    if (threadIdx.x == 0) red[16] = s;
+  }
+  __syncthreads();
+  return red[16];
+}
+
+// One row (6 doubles) of a stored upper block applied in both directions of the symmetric product.
+__device__ __forceinline__ void small_apply_row(const double b[6], int i, int j, int rr, const double* p, double* q) {
+  const double* pj = p + 6 * j;
+  double a = 0.0;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) a += b[c] * pj[c];
+  atomic_add_f64(&q[6 * i + rr], a);
+  if (i != j) {
+    const double pir = p[6 * i + rr];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) atomic_add_f64(&q[6 * j + c], b[c] * pir);
+  }
+}
+
+__device__ __forceinline__ void small_load_row(const DeviceProblem& d, int t, double lam, double min_diag,
+                                               double b[6], int& i, int& j, int& rr) {
+  const int s = t / 6;
+  rr = t - 6 * s;
+  i = d.urow[s];
+  j = d.ucol[s];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) b[c] = d.S[(long)s * 36 + 6 * rr + c];
+  const double damp = (i == j) ? lam * fmax(d.Udiag[6 * i + rr], min_diag) : 0.0;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) b[c] += (c == rr) ? damp : 0.0;  // static index: keeps b in VGPRs
+}
+
+// NC = rows of S each thread keeps in registers (the rest is streamed from L2 every iteration).
+template <int NC>
+__global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, double lam, double min_diag,
+                                                               double tol2, int max_iter) {
+  extern __shared__ double sm[];
+  const int N = 6 * d.Cf;
+  double* x = sm;
+  double* r = x + N;
+  double* z = r + N;
+  double* p = z + N;
+  double* q = p + N;
+  double* Minv = q + N;            // [Cf][36]
+  double* red = Minv + 36 * d.Cf;  // [17]
+  const int tid = threadIdx.x;
+  const int nitems = d.nu * 6;
+
+  // ---- preconditioner: inverse of the damped diagonal blocks
+  for (int f = tid; f < d.Cf; f += SMALL_THREADS) {
+    double A[36];
+    const double* Sd = d.S + (long)d.diag_slot[f] * 36;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) A[i] = Sd[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) A[7 * i] += lam * fmax(d.Udiag[6 * f + i], min_diag);
+    if (!spd_inverse6(A)) atomic_add_f64(&d.scal[SC_BADV], 1.0);
+#pragma unroll
+    for (int i = 0; i < 36; ++i) Minv[36 * f + i] = A[i];
+  }
+  __syncthreads();
+  // ---- this thread's cached rows of upper blocks (damping folded into the diagonal entries)
+  double B[NC > 0 ? NC : 1][6];
+  int ij[NC > 0 ? NC : 1];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const int t = tid + k * SMALL_THREADS;
+    ij[k] = -1;
+    if (t < nitems) {
+      int i, j, rr;
+      small_load_row(d, t, lam, min_diag, B[k], i, j, rr);
+      ij[k] = (i << 16) | j;
+    }
+  }
+  for (int t = tid; t < N; t += SMALL_THREADS) {
+    const int f = t / 6, i = t - 6 * f;
+    double zi = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) zi -= Minv[36 * f + 6 * i + c] * d.rhs[6 * f + c];
+    x[t] = 0.0;
+    r[t] = -d.rhs[t];
+    z[t] = zi;
+    p[t] = zi;
+  }
+  __syncthreads();
+  double part = 0.0;
+  for (int t = tid; t < N; t += SMALL_THREADS) part += r[t] * z[t];
+  double rz = block_sum_1024(part, red);
+  const double rz0 = rz;
+  int it = 0;
+  while (it < max_iter && rz > tol2 * rz0 && rz > 0.0) {
+    for (int t = tid; t < N; t += SMALL_THREADS) q[t] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      if (ij[k] >= 0) small_apply_row(B[k], ij[k] >> 16, ij[k] & 0xffff, (tid + k * SMALL_THREADS) % 6, p, q);
+    }
+    for (int t = tid + NC * SMALL_THREADS; t < nitems; t += SMALL_THREADS) {
+      double b[6];
+      int i, j, rr;
+      small_load_row(d, t, lam, min_diag, b, i, j, rr);
+      small_apply_row(b, i, j, rr, p, q);
+    }
+    __syncthreads();
+    part = 0.0;
+    for (int t = tid; t < N; t += SMALL_THREADS) part += p[t] * q[t];
+    const double pq = block_sum_1024(part, red);
+    if (!(pq > 0.0)) break;
+    const double alpha = rz / pq;
+    for (int t = tid; t < N; t += SMALL_THREADS) {
+      x[t] += alpha * p[t];
+      r[t] -= alpha * q[t];
+    }
+    __syncthreads();
+    part = 0.0;
+    for (int t = tid; t < N; t += SMALL_THREADS) {
+      const int f = t / 6, i = t - 6 * f;
+      double zi = 0.0;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) zi += Minv[36 * f + 6 * i + c] * r[6 * f + c];
+      z[t] = zi;
+      part += r[t] * zi;
+    }
+    const double rzn = block_sum_1024(part, red);
+    const double beta = rzn / rz;
+    for (int t = tid; t < N; t += SMALL_THREADS) p[t] = z[t] + beta * p[t];
+    rz = rzn;
+    ++it;
+    __syncthreads();
+  }
+  for (int t = tid; t < N; t += SMALL_THREADS) d.dc[t] = x[t];
+  if (tid == 0) {
+    d.scal[SC_PCGIT] = (double)it;
+    d.scal[SC_RZ] = rz;
+    d.scal[SC_RZ0] = rz0;
+    d.scal[SC_DONE] = 1.0;
   }
 }
 

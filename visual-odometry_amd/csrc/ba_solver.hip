@@ -44,7 +44,9 @@ struct ba_handle {
   std::vector<int> cam2free, free2cam;
   std::vector<int> urow_ptr, ucol;
   std::vector<uint8_t> fixed;
-  int g_lin = 16, g_schur = 64, lpg_lin = 1, lpg_schur = 1;
+  int g_lin = 16, g_schur = 64, lpg_lin = 1, lpg_schur = 1, lpg_back = 1;
+  bool small_solve = false, small_cached = false;
+  size_t small_lds = 0;
 
   DeviceProblem d{};
   std::vector<void*> allocs;  // everything to hipFree
@@ -182,15 +184,15 @@ void launch_linearize(ba_handle* h, const double* poses, const double* pts) {
 
 void launch_backsub(ba_handle* h, double lam, const double* pts, double* pts_t) {
   const DeviceProblem& d = h->d;
-  const long groups = (d.L_obs + h->lpg_lin - 1) / h->lpg_lin;
+  const long groups = (d.L_obs + h->lpg_back - 1) / h->lpg_back;
   const int G = h->g_lin;
   const int grid = grid_for(groups * G);
   const double md = h->opt.min_diag;
   switch (G) {
-    case 8: k_backsub<8><<<grid, 256, 0, h->stream>>>(d, lam, md, pts, pts_t, h->lpg_lin); break;
-    case 16: k_backsub<16><<<grid, 256, 0, h->stream>>>(d, lam, md, pts, pts_t, h->lpg_lin); break;
-    case 32: k_backsub<32><<<grid, 256, 0, h->stream>>>(d, lam, md, pts, pts_t, h->lpg_lin); break;
-    default: k_backsub<64><<<grid, 256, 0, h->stream>>>(d, lam, md, pts, pts_t, h->lpg_lin); break;
+    case 8: k_backsub<8><<<grid, 256, 0, h->stream>>>(d, lam, md, pts, pts_t, h->lpg_back); break;
+    case 16: k_backsub<16><<<grid, 256, 0, h->stream>>>(d, lam, md, pts, pts_t, h->lpg_back); break;
+    case 32: k_backsub<32><<<grid, 256, 0, h->stream>>>(d, lam, md, pts, pts_t, h->lpg_back); break;
+    default: k_backsub<64><<<grid, 256, 0, h->stream>>>(d, lam, md, pts, pts_t, h->lpg_back); break;
   }
 }
 
@@ -217,10 +219,17 @@ void launch_cost(ba_handle* h, const double* poses, const double* pts, int cost_
 // linearise at (poses, pts): zero accumulators, blocks U V W gc gp, cost into scal[SC_COST]
 int do_linearize(ba_handle* h, const double* poses, const double* pts) {
   HIP_TRY(h, hipMemsetAsync(h->d.scal, 0, SC_COUNT * sizeof(double), h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->d.Ugc, 0, (size_t)h->C * 27 * sizeof(double), h->stream));
+  {
+    KSpan t(h, KT_OTHER, 1);
+    HIP_TRY(h, hipMemsetAsync(h->d.Ugc_slab, 0, (size_t)h->d.nslab_u * h->C * 27 * sizeof(double), h->stream));
+  }
   {
     KSpan t(h, KT_LIN);
     launch_linearize(h, poses, pts);
+  }
+  {
+    KSpan t(h, KT_OTHER, 1);
+    k_reduce_U<<<grid_for(27L * h->C), 256, 0, h->stream>>>(h->d);
   }
   return BA_OK;
 }
@@ -230,13 +239,27 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
   DeviceProblem& d = h->d;
   const ba_options& o = h->opt;
   {
-    KSpan t(h, KT_OTHER, 2);
-    HIP_TRY(h, hipMemsetAsync(d.S, 0, (size_t)(d.nu + d.nl) * 36 * sizeof(double), h->stream));
-    k_schur_init<<<grid_for(d.Cf), 256, 0, h->stream>>>(d);
+    KSpan t(h, KT_OTHER, 1);
+    HIP_TRY(h, hipMemsetAsync(d.S_slab, 0, (size_t)d.nslab_s * d.s_slab_stride * sizeof(double), h->stream));
   }
   {
     KSpan t(h, KT_SCHUR);
     launch_schur(h, lam);
+  }
+  {
+    KSpan t(h, KT_OTHER, 1);
+    k_reduce_S<<<grid_for(d.s_slab_stride), 256, 0, h->stream>>>(d);
+  }
+  const double tol2 = o.pcg_tol * o.pcg_tol;
+  if (h->small_solve) {
+    KSpan t(h, KT_PCG, 1);
+    if (h->small_cached)
+      k_solve_small<SMALL_CACHED_ROWS><<<1, SMALL_THREADS, h->small_lds, h->stream>>>(d, lam, o.min_diag, tol2,
+                                                                                       o.pcg_max_iter);
+    else
+      k_solve_small<0><<<1, SMALL_THREADS, h->small_lds, h->stream>>>(d, lam, o.min_diag, tol2, o.pcg_max_iter);
+    *pcg_iters = -1;  // read from scal after the trial readback
+    return BA_OK;
   }
   {
     KSpan t(h, KT_OTHER, 1);
@@ -247,7 +270,6 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
     KSpan t(h, KT_PCG, 1);
     k_pcg_init<<<gv, 256, 0, h->stream>>>(d);
   }
-  const double tol2 = o.pcg_tol * o.pcg_tol;
   const int every = std::max(1, o.pcg_check_every);
   int launched = 0;
   while (launched < o.pcg_max_iter) {
@@ -366,6 +388,7 @@ int lm_solve(ba_handle* h, ba_report* rep) {
     if ((rc = do_reduced_solve(h, lam, &pcg_it))) return rc;
     if ((rc = do_trial(h, lam, poses, pts, poses_t, pts_t))) return rc;
     const double* s = h->scal_host;
+    if (pcg_it < 0) pcg_it = (int)s[SC_PCGIT];
     if (need_lin) {
       cost = s[SC_COST];
       nbehind = s[SC_NBEHIND];
@@ -666,10 +689,33 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
     const long groups_lin = target_waves * (64 / h->g_lin), groups_schur = target_waves * (64 / h->g_schur);
     h->lpg_lin = env_int("BA_LPG_LIN", (int)std::max<long>(1, (L_obs + groups_lin - 1) / groups_lin));
     h->lpg_schur = env_int("BA_LPG_SCHUR", (int)std::max<long>(1, (L_obs + groups_schur - 1) / groups_schur));
+    h->lpg_back = env_int("BA_LPG_BACK", 1);
+  }
+  // privatised slabs: as many copies as fit a fixed budget, so that few atomics share an address
+  {
+    const size_t u_bytes = (size_t)C * 27 * sizeof(double);
+    const size_t s_bytes = ((size_t)nu * 36 + (size_t)6 * Cf) * sizeof(double);
+    h->d.nslab_u = env_int("BA_NSLAB_U", (int)std::min<size_t>(256, std::max<size_t>(1, ((size_t)8 << 20) / u_bytes)));
+    h->d.nslab_s = env_int("BA_NSLAB_S", (int)std::min<size_t>(64, std::max<size_t>(1, ((size_t)32 << 20) / s_bytes)));
+    h->d.s_slab_stride = (long)nu * 36 + 6L * Cf;
+  }
+  // one-workgroup reduced solve for small camera systems (vectors + preconditioner in LDS)
+  {
+    h->small_lds = ((size_t)5 * 6 * Cf + (size_t)36 * Cf + 32) * sizeof(double);
+    h->small_solve = env_int("BA_SMALL_SOLVE", 1) && Cf <= 256 && h->small_lds <= 160 * 1024 &&
+                     h->opt.linear_solver != BA_SOLVER_DENSE_CHOLESKY;
+    h->small_cached = env_int("BA_SMALL_CACHED", 1) != 0;
+    if (h->small_solve && h->small_lds > 64 * 1024) {
+      HIP_TRY(h, hipFuncSetAttribute((const void*)k_solve_small<SMALL_CACHED_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)h->small_lds));
+      HIP_TRY(h, hipFuncSetAttribute((const void*)k_solve_small<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)h->small_lds));
+    }
   }
 
   // ---- upload structure, allocate state
   DeviceProblem& d = h->d;
+  const int nslab_u = d.nslab_u, nslab_s = d.nslab_s;
   d.C = C; d.Cf = Cf; d.L = L; d.L_obs = L_obs; d.n = n;
   d.K = Intrinsics{intr[0], intr[1], intr[2], intr[3], intr[4], intr[5], intr[6],
                    (intr[4] != 0.0 || intr[5] != 0.0 || intr[6] != 0.0) ? 1 : 0};
@@ -687,6 +733,8 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
   if ((rc = dev_alloc(h, &d.W, (size_t)18 * n)) || (rc = dev_alloc(h, &d.V, (size_t)6 * L)) ||
       (rc = dev_alloc(h, &d.gp, (size_t)3 * L)) || (rc = dev_alloc(h, &d.Ugc, (size_t)27 * C)) ||
       (rc = dev_alloc(h, &d.S, (size_t)36 * (nu + nl))) || (rc = dev_alloc(h, &d.rhs, (size_t)6 * Cf)) ||
+      (rc = dev_alloc(h, &d.Ugc_slab, (size_t)nslab_u * 27 * C)) ||
+      (rc = dev_alloc(h, &d.S_slab, (size_t)nslab_s * d.s_slab_stride)) ||
       (rc = dev_alloc(h, &d.Udiag, (size_t)6 * Cf)) || (rc = dev_alloc(h, &d.Minv, (size_t)36 * Cf)) ||
       (rc = dev_alloc(h, &d.dc, (size_t)6 * Cf)) || (rc = dev_alloc(h, &d.r, (size_t)6 * Cf)) ||
       (rc = dev_alloc(h, &d.z, (size_t)6 * Cf)) || (rc = dev_alloc(h, &d.p, (size_t)6 * Cf)) ||
