@@ -231,3 +231,31 @@ __device__ __forceinline__ double block_max_256(double v, double* red) {
   }
   return s;
 }
+
+// Wave-cooperative scatter-add.  Every lane with `valid` has staged NV doubles in LDS row
+// stage[lane * STRIDE .. + NV) that must be added to dst[key .. key + NV).  Lanes whose keys are
+// equal are summed first; then ONE atomic wave-instruction adds the NV contiguous doubles of a
+// target (contiguous fp64 atomics run at the full memory-side rate, one-lane-per-row scatter an order
+// of magnitude slower -- MI355X_MICROARCH.md "Global float atomics").  Call from ALL lanes of a
+// 64-thread block (one wave), after a barrier that makes the staged rows visible.
+template <int NV, int STRIDE>
+__device__ __forceinline__ void wave_scatter_add(const double* stage, bool valid, long key, double* dst) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(valid);
+  while (todo) {
+    const int b = __ffsll((long long)todo) - 1;
+    const long kb = __shfl(key, b);
+    const unsigned long long same = __ballot(valid && key == kb);
+    if (lane < NV) {
+      double s = 0.0;
+      unsigned long long m = same;
+      while (m) {
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        s += stage[l * STRIDE + lane];
+      }
+      atomic_add_f64(dst + kb + lane, s);
+    }
+    todo &= ~same;
+  }
+}

@@ -21,12 +21,18 @@ enum ScalarSlot {
   SC_RZ = 16, SC_RZ0, SC_PQ, SC_RZNEW, SC_DONE, SC_PCGIT,
   SC_COUNT = 32
 };
+// Scalar accumulators are privatised too: block b adds into copy (b mod SCAL_SLABS); the host sums
+// (max for SC_GINF) the copies after the read-back.  Same-address fp64 atomics from hundreds of
+// blocks otherwise serialise at the memory side and dominate these short kernels.
+constexpr int SCAL_SLABS = 64;
+#define SCAL_MINE(d) ((d).scal + (size_t)(blockIdx.x & (SCAL_SLABS - 1)) * SC_COUNT)
 
 struct DeviceProblem {
   int C, Cf, L, L_obs, n;  // cameras, free cameras, landmarks, landmarks with >= 1 observation, observations
   Intrinsics K;
   // structure (constant per problem)
   const int* o_cam; const double* o_u; const double* o_v; const int* o_src; const int* o_lm;
+  const int* o_free;     // [n]  free-camera index of the observation's image, -1 = fixed pose
   const int* lm_ptr;     // [L_obs + 1]
   const int* cam2free;   // [C]   -1 = fixed
   const int* free2cam;   // [Cf]
@@ -38,6 +44,7 @@ struct DeviceProblem {
   const int* brow_ptr;   // [Cf + 1] full (both triangles) block rows for SpMV
   const int* bcol;       // [nb]
   const int* bslot;      // [nb]
+  const int* sm_slot;    // [nu]  upper slots in diagonal-major order (k_solve_small item order)
   int nu, nl, nb;
   // state
   double* W; double* V; double* gp; double* Ugc;
@@ -60,30 +67,61 @@ struct DeviceProblem {
 // ordered by camera signature, so runs are long) and flushed with one fp64 atomic per entry per run.
 // Algorithmic bytes: read 20 B/obs (cam idx + u + v) + 24 B/landmark (P), write W 144 B/obs,
 // V 48 + gp 24 B/landmark, U/gc 216 B per camera run.
+constexpr int LIN_STRIDE = 29;    // 27 values + pad (odd number of doubles: 2-way LDS write conflicts at most)
+constexpr int SCHUR_STRIDE = 37;  // 36 values + pad
+
+#ifndef LIN_WAVES
+#define LIN_WAVES 2
+#endif
 template <int G>
-__global__ __launch_bounds__(256) void k_linearize(DeviceProblem d, const double* __restrict__ poses,
-                                                   const double* __restrict__ pts, int lm_per_group) {
-  __shared__ double red[4];
-  const int lane = threadIdx.x & (G - 1);
-  const long group = ((long)blockIdx.x * blockDim.x + threadIdx.x) / G;
-  const long j0 = group * lm_per_group;
+__global__ __launch_bounds__(64, LIN_WAVES) void k_linearize(DeviceProblem d, const double* __restrict__ poses,
+                                                  const double* __restrict__ pts, int lm_per_group) {
+  __shared__ double stage[64 * LIN_STRIDE];
+  const int lane = threadIdx.x;  // one wave per block
+  const int gl = lane & (G - 1);
+  const long group = ((long)blockIdx.x * 64 + lane) / G;
+  const long j0 = min((long)d.L_obs, group * lm_per_group);
   const long j1 = min((long)d.L_obs, j0 + lm_per_group);
   const long n = d.n;
-  double* __restrict__ Uslab = d.Ugc_slab + (long)(group % d.nslab_u) * d.C * 27;
+  double* __restrict__ Uslab = d.Ugc_slab + (long)(blockIdx.x % d.nslab_u) * d.C * 27;
   double acc[27];
 #pragma unroll
   for (int i = 0; i < 27; ++i) acc[i] = 0.0;
   int cur_cam = -1;
   double cost = 0.0, gmax = 0.0;
   int nbehind = 0, nzero = 0;
-  for (long j = j0; j < j1; ++j) {
-    const int kb = d.lm_ptr[j], ke = d.lm_ptr[j + 1];
-    const double P[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
+
+  auto flush = [&]() {  // wave-uniform: every lane calls it
+    if (cur_cam >= 0) {
+#pragma unroll
+      for (int i = 0; i < 27; ++i) stage[lane * LIN_STRIDE + i] = acc[i];
+    }
+    __syncthreads();
+    wave_scatter_add<27, LIN_STRIDE>(stage, cur_cam >= 0, (long)cur_cam * 27, Uslab);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+    cur_cam = -1;
+  };
+
+  for (int jj = 0; jj < lm_per_group; ++jj) {
+    const long j = j0 + jj;
+    const bool lm_ok = j < j1;
+    int kb = 0, ke = 0;
+    double P[3] = {0, 0, 0};
+    if (lm_ok) {
+      kb = d.lm_ptr[j]; ke = d.lm_ptr[j + 1];
+      P[0] = pts[3 * j]; P[1] = pts[3 * j + 1]; P[2] = pts[3 * j + 2];
+    }
     double v[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-    for (int k0 = kb; k0 < ke; k0 += G) {
-      const int k = k0 + lane;
-      if (k < ke) {
-        const int cam = d.o_cam[k];
+    for (int k0 = kb; __any(k0 < ke); k0 += G) {
+      const int k = k0 + gl;
+      const bool act = k < ke;
+      const int cam = act ? d.o_cam[k] : -1;
+      const bool is_free = act && d.cam2free[cam] >= 0;
+      // flush BEFORE the linearisation so that only the accumulators are live across it
+      if (__any(is_free && cur_cam >= 0 && cam != cur_cam)) flush();
+      if (act) {
         double r[2], Jc[12], Jp[6], zc;
         linearize_obs(d.K, poses + 7 * cam, P, d.o_u[k], d.o_v[k], r, Jc, Jp, zc);
         nbehind += (zc <= 0.0);
@@ -98,7 +136,6 @@ __global__ __launch_bounds__(256) void k_linearize(DeviceProblem d, const double
         g[0] += Jp[0] * r[0] + Jp[3] * r[1];
         g[1] += Jp[1] * r[0] + Jp[4] * r[1];
         g[2] += Jp[2] * r[0] + Jp[5] * r[1];
-        const bool is_free = d.cam2free[cam] >= 0;
         if (!is_free) {
 #pragma unroll
           for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
@@ -108,15 +145,7 @@ __global__ __launch_bounds__(256) void k_linearize(DeviceProblem d, const double
 #pragma unroll
           for (int c = 0; c < 3; ++c) d.W[(long)(3 * i + c) * n + k] = Jc[i] * Jp[c] + Jc[6 + i] * Jp[3 + c];
         if (is_free) {
-          if (cam != cur_cam) {
-            if (cur_cam >= 0) {
-#pragma unroll
-              for (int i = 0; i < 27; ++i) atomic_add_f64(&Uslab[(long)cur_cam * 27 + i], acc[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < 27; ++i) acc[i] = 0.0;
-            cur_cam = cam;
-          }
+          cur_cam = cam;
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
 #pragma unroll
@@ -130,7 +159,7 @@ __global__ __launch_bounds__(256) void k_linearize(DeviceProblem d, const double
     for (int i = 0; i < 6; ++i) v[i] = group_sum<G>(v[i]);
 #pragma unroll
     for (int i = 0; i < 3; ++i) g[i] = group_sum<G>(g[i]);
-    if (lane == 0) {
+    if (gl == 0 && lm_ok) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) d.V[(long)i * d.L + j] = v[i];
 #pragma unroll
@@ -138,19 +167,16 @@ __global__ __launch_bounds__(256) void k_linearize(DeviceProblem d, const double
       gmax = fmax(gmax, fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2]))));
     }
   }
-  if (cur_cam >= 0) {
-#pragma unroll
-    for (int i = 0; i < 27; ++i) atomic_add_f64(&Uslab[(long)cur_cam * 27 + i], acc[i]);
-  }
-  const double bc = block_sum_256(cost, red);
-  const double bb = block_sum_256((double)nbehind, red);
-  const double bz = block_sum_256((double)nzero, red);
-  const double bg = block_max_256(gmax, red);
-  if (threadIdx.x == 0) {
-    atomic_add_f64(&d.scal[SC_COST], bc);
-    if (bb != 0.0) atomic_add_f64(&d.scal[SC_NBEHIND], bb);
-    if (bz != 0.0) atomic_add_f64(&d.scal[SC_ZEROZ], bz);
-    atomic_max_nonneg(&d.scal[SC_GINF], bg);
+  flush();
+  cost = group_sum<64>(cost);
+  gmax = group_max<64>(gmax);
+  const double bb = group_sum<64>((double)nbehind), bz = group_sum<64>((double)nzero);
+  if (lane == 0) {
+    double* sc = SCAL_MINE(d);
+    atomic_add_f64(&sc[SC_COST], cost);
+    if (bb != 0.0) atomic_add_f64(&sc[SC_NBEHIND], bb);
+    if (bz != 0.0) atomic_add_f64(&sc[SC_ZEROZ], bz);
+    atomic_max_nonneg(&sc[SC_GINF], gmax);
   }
 }
 
@@ -184,9 +210,10 @@ __global__ __launch_bounds__(256) void k_cost(DeviceProblem d,
   const double bb = block_sum_256((double)nbehind, red);
   const double bz = block_sum_256((double)nzero, red);
   if (threadIdx.x == 0) {
-    atomic_add_f64(&d.scal[cost_slot], bc);
-    if (bb != 0.0) atomic_add_f64(&d.scal[behind_slot], bb);
-    if (bz != 0.0) atomic_add_f64(&d.scal[SC_ZEROZ], bz);
+    double* sc = SCAL_MINE(d);
+    atomic_add_f64(&sc[cost_slot], bc);
+    if (bb != 0.0) atomic_add_f64(&sc[behind_slot], bb);
+    if (bz != 0.0) atomic_add_f64(&sc[SC_ZEROZ], bz);
   }
 }
 
@@ -211,18 +238,28 @@ __global__ __launch_bounds__(256) void k_export_jac(DeviceProblem d,
 // k_reduce_U: Ugc[c][e] = sum over slabs; inf-norm of the camera gradient.  One thread per entry.
 __global__ __launch_bounds__(256) void k_reduce_U(DeviceProblem d) {
   __shared__ double red[4];
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  // 16 entries x 16 slab-lanes per block: lane l sums slabs l, l+16, ...; shuffle-reduce over lanes
+  const int e_in_blk = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long t = (long)blockIdx.x * 16 + e_in_blk;
   const long tot = (long)d.C * 27;
+  double sum = 0.0;
+  if (t < tot)
+    for (int k = sl; k < d.nslab_u; k += 16) sum += d.Ugc_slab[(long)k * tot + t];
+  // lanes of one entry are 16 apart inside the block: combine through LDS
+  __shared__ double part[256];
+  part[threadIdx.x] = sum;
+  __syncthreads();
   double gmax = 0.0;
-  if (t < tot) {
-    double sum = 0.0;
-    for (int k = 0; k < d.nslab_u; ++k) sum += d.Ugc_slab[(long)k * tot + t];
-    d.Ugc[t] = sum;
+  if (threadIdx.x < 16 && t < tot) {
+    double tsum = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tsum += part[threadIdx.x + 16 * k];
+    d.Ugc[t] = tsum;
     const int cam = (int)(t / 27), e = (int)(t - 27L * cam);
-    if (e >= 21 && d.cam2free[cam] >= 0) gmax = fabs(sum);
+    if (e >= 21 && d.cam2free[cam] >= 0) gmax = fabs(tsum);
   }
   const double bg = block_max_256(gmax, red);
-  if (threadIdx.x == 0) atomic_max_nonneg(&d.scal[SC_GINF], bg);
+  if (threadIdx.x == 0 && bg > 0.0) atomic_max_nonneg(&SCAL_MINE(d)[SC_GINF], bg);
 }
 
 // k_reduce_S: S (upper blocks) = sum of the slabs (+ U on the diagonal blocks), rhs = gc + sum of
@@ -269,10 +306,13 @@ __device__ __forceinline__ int upper_slot(const DeviceProblem& d, int fa, int fb
 // per run.  Algorithmic bytes: W 144 B/obs (each W is re-read by the lanes of its track from L1/L2),
 // V 48 + gp 24 B/landmark, 4 B/obs camera index; S writes 288 B per (pair, run).
 template <int G>
-__global__ __launch_bounds__(256) void k_schur(DeviceProblem d, double lam, double min_diag, int lm_per_group) {
-  const int lane = threadIdx.x & (G - 1);
-  const long group = ((long)blockIdx.x * blockDim.x + threadIdx.x) / G;
-  const long j0 = group * lm_per_group;
+__global__ __launch_bounds__(64, 2) void k_schur(DeviceProblem d, double lam, double min_diag, int lm_per_group) {
+  __shared__ double stage[64 * SCHUR_STRIDE];
+  __shared__ double stage_r[64 * 7];
+  const int lane = threadIdx.x;  // one wave per block
+  const int gl = lane & (G - 1);
+  const long group = ((long)blockIdx.x * 64 + lane) / G;
+  const long j0 = min((long)d.L_obs, group * lm_per_group);
   const long j1 = min((long)d.L_obs, j0 + lm_per_group);
   const long n = d.n;
   double acc[36], accr[6];
@@ -283,78 +323,115 @@ __global__ __launch_bounds__(256) void k_schur(DeviceProblem d, double lam, doub
   int cur_a = -1, cur_b = -1;
   bool cur_sym = false;
   int nbad = 0;
-  double* __restrict__ Sslab = d.S_slab + (long)(group % d.nslab_s) * d.s_slab_stride;
+  double* __restrict__ Sslab = d.S_slab + (long)(blockIdx.x % d.nslab_s) * d.s_slab_stride;
   double* __restrict__ Rslab = Sslab + (long)d.nu * 36;
 
-  auto flush = [&]() {
-    if (cur_a < 0) return;
-    double* Sb = Sslab + (long)upper_slot(d, cur_a, cur_b) * 36;
-    if (cur_sym) {  // two observations of one landmark in the same image: add block + block^T
+  auto flush = [&]() {  // wave-uniform: every lane calls it
+    const bool have = cur_a >= 0;
+    const bool diag = have && cur_a == cur_b && !cur_sym;
+    long key = 0;
+    if (have) {
+      key = (long)upper_slot(d, cur_a, cur_b) * 36;
+      if (cur_sym) {  // two observations of one landmark in the same image: block + block^T
 #pragma unroll
-      for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int c = 0; c < 6; ++c) atomic_add_f64(&Sb[6 * i + c], -(acc[6 * i + c] + acc[6 * c + i]));
-    } else {
+          for (int c = 0; c < 6; ++c) stage[lane * SCHUR_STRIDE + 6 * i + c] = -(acc[6 * i + c] + acc[6 * c + i]);
+      } else {
 #pragma unroll
-      for (int i = 0; i < 36; ++i) atomic_add_f64(&Sb[i], -acc[i]);
+        for (int i = 0; i < 36; ++i) stage[lane * SCHUR_STRIDE + i] = -acc[i];
+      }
+      if (diag) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) stage_r[lane * 7 + i] = -accr[i];
+      }
     }
-    if (cur_a == cur_b && !cur_sym) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) atomic_add_f64(&Rslab[6 * cur_a + i], -accr[i]);
-    }
+    __syncthreads();
+    wave_scatter_add<36, SCHUR_STRIDE>(stage, have, key, Sslab);
+    wave_scatter_add<6, 7>(stage_r, diag, 6L * cur_a, Rslab);
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 36; ++i) acc[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) accr[i] = 0.0;
+    cur_a = -1;
+    cur_b = -1;
+    cur_sym = false;
   };
 
-  for (long j = j0; j < j1; ++j) {
-    const int kb = d.lm_ptr[j];
-    const int len = d.lm_ptr[j + 1] - kb;
-    const int npairs = len * (len + 1) / 2;
-    double v[6], vi[6], g[3];
+  // pair owned by this lane in the first pass: p = gl = b (b + 1) / 2 + a, a <= b (static per lane)
+  int b0 = (int)((sqrt(8.0 * gl + 1.0) - 1.0) * 0.5);
+  while ((b0 + 1) * (b0 + 2) / 2 <= gl) ++b0;
+  while (b0 * (b0 + 1) / 2 > gl) --b0;
+  const int a0 = gl - b0 * (b0 + 1) / 2;
+  // software prefetch: the track bounds and this lane's camera pair of landmark j + 1 are loaded
+  // while landmark j is being processed (removes two dependent round trips per landmark)
+  int kb_n = 0, np_n = 0, fa_n = -1, fb_n = -1;
+  auto prefetch = [&](long j) {
+    kb_n = 0; np_n = 0; fa_n = -1; fb_n = -1;
+    if (j < j1) {
+      kb_n = d.lm_ptr[j];
+      const int len = d.lm_ptr[j + 1] - kb_n;
+      np_n = len * (len + 1) / 2;
+      if (gl < np_n) { fa_n = d.o_free[kb_n + a0]; fb_n = d.o_free[kb_n + b0]; }
+    }
+  };
+  prefetch(j0);
+  for (int jj = 0; jj < lm_per_group; ++jj) {
+    const long j = j0 + jj;
+    const bool lm_ok = j < j1;
+    const int kb = kb_n, npairs = np_n, fa_first = fa_n, fb_first = fb_n;
+    prefetch(j + 1);
+    double v[6] = {1, 0, 0, 1, 0, 1}, vi[6], g[3] = {0, 0, 0};
+    if (lm_ok) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) v[i] = d.V[(long)i * d.L + j];
+      for (int i = 0; i < 6; ++i) v[i] = d.V[(long)i * d.L + j];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) g[i] = d.gp[(long)i * d.L + j];
+      for (int i = 0; i < 3; ++i) g[i] = d.gp[(long)i * d.L + j];
+    }
     const double det = damped_inv3(v, lam, min_diag, vi);
-    if (!(det > 0.0) && lane == 0) ++nbad;
-    for (int p = lane; p < npairs; p += G) {
-      // decode p = b (b + 1) / 2 + a,  a <= b
-      int b = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
-      while ((b + 1) * (b + 2) / 2 <= p) ++b;
-      while (b * (b + 1) / 2 > p) --b;
-      const int a = p - b * (b + 1) / 2;
-      const int ka = kb + a, kbb = kb + b;
-      const int fa = d.cam2free[d.o_cam[ka]], fb = d.cam2free[d.o_cam[kbb]];
-      if (fa < 0 || fb < 0) continue;
-      const bool sym = (fa == fb) && (a != b);
-      if (fa != cur_a || fb != cur_b || sym != cur_sym) {
-        flush();
+    if (lm_ok && !(det > 0.0) && gl == 0) ++nbad;
+    for (int p0 = 0; __any(p0 < npairs); p0 += G) {
+      const int p = p0 + gl;
+      bool act = p < npairs;
+      int a = a0, b = b0, fa = fa_first, fb = fb_first;
+      if (act && p0 > 0) {
+        b = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
+        while ((b + 1) * (b + 2) / 2 <= p) ++b;
+        while (b * (b + 1) / 2 > p) --b;
+        a = p - b * (b + 1) / 2;
+        fa = d.o_free[kb + a];
+        fb = d.o_free[kb + b];
+      }
+      act = act && fa >= 0 && fb >= 0;
+      const bool sym = act && (fa == fb) && (a != b);
+      if (__any(act && cur_a >= 0 && (fa != cur_a || fb != cur_b || sym != cur_sym))) flush();
+      if (act) {
         cur_a = fa; cur_b = fb; cur_sym = sym;
-      }
-      double Y[18];
+        const int ka = kb + a, kbb = kb + b;
+        double Y[18];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const double w[3] = {d.W[(long)(3 * i) * n + ka], d.W[(long)(3 * i + 1) * n + ka],
-                             d.W[(long)(3 * i + 2) * n + ka]};
-        sym3_mul(vi, w, &Y[3 * i]);
-      }
-      if (a == b) {
+        for (int i = 0; i < 6; ++i) {
+          const double w[3] = {d.W[(long)(3 * i) * n + ka], d.W[(long)(3 * i + 1) * n + ka],
+                               d.W[(long)(3 * i + 2) * n + ka]};
+          sym3_mul(vi, w, &Y[3 * i]);
+        }
+        if (a == b) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) accr[i] += Y[3 * i] * g[0] + Y[3 * i + 1] * g[1] + Y[3 * i + 2] * g[2];
-      }
+          for (int i = 0; i < 6; ++i) accr[i] += Y[3 * i] * g[0] + Y[3 * i + 1] * g[1] + Y[3 * i + 2] * g[2];
+        }
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const double w0 = d.W[(long)(3 * c) * n + kbb], w1 = d.W[(long)(3 * c + 1) * n + kbb],
-                     w2 = d.W[(long)(3 * c + 2) * n + kbb];
+        for (int c = 0; c < 6; ++c) {
+          const double w0 = d.W[(long)(3 * c) * n + kbb], w1 = d.W[(long)(3 * c + 1) * n + kbb],
+                       w2 = d.W[(long)(3 * c + 2) * n + kbb];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc[6 * i + c] += Y[3 * i] * w0 + Y[3 * i + 1] * w1 + Y[3 * i + 2] * w2;
+          for (int i = 0; i < 6; ++i) acc[6 * i + c] += Y[3 * i] * w0 + Y[3 * i + 1] * w1 + Y[3 * i + 2] * w2;
+        }
       }
     }
   }
   flush();
-  if (nbad) atomic_add_f64(&d.scal[SC_BADV], (double)nbad);
+  if (nbad) atomic_add_f64(&SCAL_MINE(d)[SC_BADV], (double)nbad);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -496,149 +573,187 @@ __global__ __launch_bounds__(256) void k_pcg_dir(DeviceProblem d, double tol2, i
 // memory at all; otherwise S is streamed from L2 every iteration.  SpMV uses the symmetry:
 // q_i += B p_j and q_j += B^T p_i for every stored upper block B = S_ij (LDS fp64 atomics).
 // Bound: latency (barriers + LDS), not HBM: S is read once (288 B per block).
-constexpr int SMALL_THREADS = 1024;
-constexpr int SMALL_CACHED_ROWS = 4;
+// k_block_precond: Minv_f = (S_ff + lam * max(diag U_f, min_diag))^-1, one thread per free camera.
+__global__ __launch_bounds__(64) void k_block_precond(DeviceProblem d, double lam, double min_diag) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= d.Cf) return;
+  double A[36];
+  const double* Sd = d.S + (long)d.diag_slot[f] * 36;
+#pragma unroll
+  for (int i = 0; i < 36; ++i) A[i] = Sd[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) A[7 * i] += lam * fmax(d.Udiag[6 * f + i], min_diag);
+  if (!spd_inverse6(A)) atomic_add_f64(&d.scal[SC_BADV], 1.0);
+#pragma unroll
+  for (int i = 0; i < 36; ++i) d.Minv[(long)f * 36 + i] = A[i];
+}
 
-__device__ __forceinline__ double block_sum_1024(double v, double* red /*[17]*/) {
+constexpr int SMALL_THREADS = 512;
+constexpr int SMALL_VPT = 2;  // vector entries per thread: 6 * Cf <= SMALL_VPT * SMALL_THREADS
+
+// Sum over the 512-thread block with ONE barrier: wave shuffle -> red[w] -> barrier -> every thread
+// adds the 8 partials itself.  `red` must not be the array used by the previous call.
+__device__ __forceinline__ double block_sum_small(double v, double* red /*[8]*/) {
   v = group_sum<64>(v);
-  __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  if (threadIdx.x < 64) {
-    double s = threadIdx.x < (SMALL_THREADS / 64) ? red[threadIdx.x] : 0.0;
-    s = group_sum<64>(s);
-    if (threadIdx.x == 0) red[16] = s;
-  }
-  __syncthreads();
-  return red[16];
+  double s = 0.0;
+#pragma unroll
+  for (int w = 0; w < SMALL_THREADS / 64; ++w) s += red[w];
+  return s;
 }
 
-// One row (6 doubles) of a stored upper block applied in both directions of the symmetric product.
-__device__ __forceinline__ void small_apply_row(const double b[6], int i, int j, int rr, const double* p, double* q) {
-  const double* pj = p + 6 * j;
-  double a = 0.0;
+// One stored upper block B = S_ij applied in both directions of the symmetric product:
+// q_i += B p_j and (i != j) q_j += B^T p_i.  Blocks are handed to threads along block diagonals
+// (sm_slot), so the 64 lanes of a wave-instruction hit 64 different i (and j): no LDS conflicts.
+__device__ __forceinline__ void small_apply_block(const double B[36], int i, int j, const double* p, double* q) {
+  double pj[6], pi[6];
 #pragma unroll
-  for (int c = 0; c < 6; ++c) a += b[c] * pj[c];
-  atomic_add_f64(&q[6 * i + rr], a);
+  for (int c = 0; c < 6; ++c) { pj[c] = p[6 * j + c]; pi[c] = p[6 * i + c]; }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    double a = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) a += B[6 * r + c] * pj[c];
+    atomic_add_f64(&q[6 * i + r], a);
+  }
   if (i != j) {
-    const double pir = p[6 * i + rr];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) atomic_add_f64(&q[6 * j + c], b[c] * pir);
+    for (int c = 0; c < 6; ++c) {
+      double a = 0.0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) a += B[6 * r + c] * pi[r];
+      atomic_add_f64(&q[6 * j + c], a);
+    }
   }
 }
 
-__device__ __forceinline__ void small_load_row(const DeviceProblem& d, int t, double lam, double min_diag,
-                                               double b[6], int& i, int& j, int& rr) {
-  const int s = t / 6;
-  rr = t - 6 * s;
+__device__ __forceinline__ void small_load_block(const DeviceProblem& d, int t, double lam, double min_diag,
+                                                 double B[36], int& i, int& j) {
+  const int s = d.sm_slot[t];
   i = d.urow[s];
   j = d.ucol[s];
 #pragma unroll
-  for (int c = 0; c < 6; ++c) b[c] = d.S[(long)s * 36 + 6 * rr + c];
-  const double damp = (i == j) ? lam * fmax(d.Udiag[6 * i + rr], min_diag) : 0.0;
+  for (int e = 0; e < 36; ++e) B[e] = d.S[(long)s * 36 + e];
+  if (i == j) {
 #pragma unroll
-  for (int c = 0; c < 6; ++c) b[c] += (c == rr) ? damp : 0.0;  // static index: keeps b in VGPRs
+    for (int e = 0; e < 6; ++e) B[7 * e] += lam * fmax(d.Udiag[6 * i + e], min_diag);
+  }
 }
 
-// NC = rows of S each thread keeps in registers (the rest is streamed from L2 every iteration).
-template <int NC>
+// NB = upper blocks of S each thread keeps in registers (further blocks are streamed from L2 every
+// iteration).  4 barriers per PCG iteration; x, z stay in registers, r is double-buffered in LDS.
+template <int NB>
 __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, double lam, double min_diag,
                                                                double tol2, int max_iter) {
   extern __shared__ double sm[];
   const int N = 6 * d.Cf;
-  double* x = sm;
-  double* r = x + N;
-  double* z = r + N;
-  double* p = z + N;
+  double* rbuf[2] = {sm, sm + N};
+  double* p = sm + 2 * N;
   double* q = p + N;
-  double* Minv = q + N;            // [Cf][36]
-  double* red = Minv + 36 * d.Cf;  // [17]
+  double* Minv = q + N;             // [Cf][36]
+  double* redA = Minv + 36 * d.Cf;  // [8]
+  double* redB = redA + 8;          // [8]
   const int tid = threadIdx.x;
-  const int nitems = d.nu * 6;
 
-  // ---- preconditioner: inverse of the damped diagonal blocks
-  for (int f = tid; f < d.Cf; f += SMALL_THREADS) {
-    double A[36];
-    const double* Sd = d.S + (long)d.diag_slot[f] * 36;
+  for (int t = tid; t < 36 * d.Cf; t += SMALL_THREADS) Minv[t] = d.Minv[t];
+  for (int t = tid; t < N; t += SMALL_THREADS) rbuf[0][t] = -d.rhs[t];
+  double B[NB][36];
+  int ij[NB];
 #pragma unroll
-    for (int i = 0; i < 36; ++i) A[i] = Sd[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) A[7 * i] += lam * fmax(d.Udiag[6 * f + i], min_diag);
-    if (!spd_inverse6(A)) atomic_add_f64(&d.scal[SC_BADV], 1.0);
-#pragma unroll
-    for (int i = 0; i < 36; ++i) Minv[36 * f + i] = A[i];
-  }
-  __syncthreads();
-  // ---- this thread's cached rows of upper blocks (damping folded into the diagonal entries)
-  double B[NC > 0 ? NC : 1][6];
-  int ij[NC > 0 ? NC : 1];
-#pragma unroll
-  for (int k = 0; k < NC; ++k) {
+  for (int k = 0; k < NB; ++k) {
     const int t = tid + k * SMALL_THREADS;
     ij[k] = -1;
-    if (t < nitems) {
-      int i, j, rr;
-      small_load_row(d, t, lam, min_diag, B[k], i, j, rr);
+    if (t < d.nu) {
+      int i, j;
+      small_load_block(d, t, lam, min_diag, B[k], i, j);
       ij[k] = (i << 16) | j;
     }
   }
-  for (int t = tid; t < N; t += SMALL_THREADS) {
-    const int f = t / 6, i = t - 6 * f;
-    double zi = 0.0;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) zi -= Minv[36 * f + 6 * i + c] * d.rhs[6 * f + c];
-    x[t] = 0.0;
-    r[t] = -d.rhs[t];
-    z[t] = zi;
-    p[t] = zi;
-  }
   __syncthreads();
+  double x[SMALL_VPT], z[SMALL_VPT];
   double part = 0.0;
-  for (int t = tid; t < N; t += SMALL_THREADS) part += r[t] * z[t];
-  double rz = block_sum_1024(part, red);
-  const double rz0 = rz;
-  int it = 0;
-  while (it < max_iter && rz > tol2 * rz0 && rz > 0.0) {
-    for (int t = tid; t < N; t += SMALL_THREADS) q[t] = 0.0;
-    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < NC; ++k) {
-      if (ij[k] >= 0) small_apply_row(B[k], ij[k] >> 16, ij[k] & 0xffff, (tid + k * SMALL_THREADS) % 6, p, q);
-    }
-    for (int t = tid + NC * SMALL_THREADS; t < nitems; t += SMALL_THREADS) {
-      double b[6];
-      int i, j, rr;
-      small_load_row(d, t, lam, min_diag, b, i, j, rr);
-      small_apply_row(b, i, j, rr, p, q);
-    }
-    __syncthreads();
-    part = 0.0;
-    for (int t = tid; t < N; t += SMALL_THREADS) part += p[t] * q[t];
-    const double pq = block_sum_1024(part, red);
-    if (!(pq > 0.0)) break;
-    const double alpha = rz / pq;
-    for (int t = tid; t < N; t += SMALL_THREADS) {
-      x[t] += alpha * p[t];
-      r[t] -= alpha * q[t];
-    }
-    __syncthreads();
-    part = 0.0;
-    for (int t = tid; t < N; t += SMALL_THREADS) {
+  for (int v = 0; v < SMALL_VPT; ++v) {
+    const int t = tid + v * SMALL_THREADS;
+    x[v] = 0.0;
+    z[v] = 0.0;
+    if (t < N) {
       const int f = t / 6, i = t - 6 * f;
       double zi = 0.0;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) zi += Minv[36 * f + 6 * i + c] * r[6 * f + c];
-      z[t] = zi;
-      part += r[t] * zi;
+      for (int c = 0; c < 6; ++c) zi += Minv[36 * f + 6 * i + c] * rbuf[0][6 * f + c];
+      z[v] = zi;
+      p[t] = zi;
+      q[t] = 0.0;
+      part += rbuf[0][t] * zi;
     }
-    const double rzn = block_sum_1024(part, red);
+  }
+  double rz = block_sum_small(part, redB);  // barrier inside: p, q visible afterwards
+  const double rz0 = rz;
+  int it = 0, cur = 0;
+  while (it < max_iter && rz > tol2 * rz0 && rz > 0.0) {
+    // (A) q = S p
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+      if (ij[k] >= 0) small_apply_block(B[k], ij[k] >> 16, ij[k] & 0xffff, p, q);
+    for (int t = tid + NB * SMALL_THREADS; t < d.nu; t += SMALL_THREADS) {
+      double Bs[36];
+      int i, j;
+      small_load_block(d, t, lam, min_diag, Bs, i, j);
+      small_apply_block(Bs, i, j, p, q);
+    }
+    __syncthreads();
+    // (B) p.q
+    part = 0.0;
+#pragma unroll
+    for (int v = 0; v < SMALL_VPT; ++v) {
+      const int t = tid + v * SMALL_THREADS;
+      if (t < N) part += p[t] * q[t];
+    }
+    const double pq = block_sum_small(part, redA);
+    if (!(pq > 0.0)) break;
+    const double alpha = rz / pq;
+    // (C) x += alpha p; r' = r - alpha q (other buffer); z = Minv r'; r'.z
+    const double* ro = rbuf[cur];
+    double* rn = rbuf[cur ^ 1];
+    part = 0.0;
+#pragma unroll
+    for (int v = 0; v < SMALL_VPT; ++v) {
+      const int t = tid + v * SMALL_THREADS;
+      if (t < N) {
+        const int f = t / 6, i = t - 6 * f;
+        double zi = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) zi += Minv[36 * f + 6 * i + c] * (ro[6 * f + c] - alpha * q[6 * f + c]);
+        const double rt = ro[t] - alpha * q[t];
+        rn[t] = rt;
+        x[v] += alpha * p[t];
+        z[v] = zi;
+        part += rt * zi;
+      }
+    }
+    const double rzn = block_sum_small(part, redB);
     const double beta = rzn / rz;
-    for (int t = tid; t < N; t += SMALL_THREADS) p[t] = z[t] + beta * p[t];
+    // (D) p = z + beta p; clear q
+#pragma unroll
+    for (int v = 0; v < SMALL_VPT; ++v) {
+      const int t = tid + v * SMALL_THREADS;
+      if (t < N) {
+        p[t] = z[v] + beta * p[t];
+        q[t] = 0.0;
+      }
+    }
     rz = rzn;
+    cur ^= 1;
     ++it;
     __syncthreads();
   }
-  for (int t = tid; t < N; t += SMALL_THREADS) d.dc[t] = x[t];
+#pragma unroll
+  for (int v = 0; v < SMALL_VPT; ++v) {
+    const int t = tid + v * SMALL_THREADS;
+    if (t < N) d.dc[t] = x[v];
+  }
   if (tid == 0) {
     d.scal[SC_PCGIT] = (double)it;
     d.scal[SC_RZ] = rz;
@@ -690,10 +805,11 @@ __global__ __launch_bounds__(256) void k_pose_update(DeviceProblem d, const doub
   const double b0 = block_sum_256(gd, red), b1 = block_sum_256(dhd, red), b2 = block_sum_256(dn, red),
                b3 = block_sum_256(xn, red);
   if (threadIdx.x == 0) {
-    atomic_add_f64(&d.scal[SC_GDOT], b0);
-    atomic_add_f64(&d.scal[SC_DHD], b1);
-    atomic_add_f64(&d.scal[SC_DNORM2], b2);
-    atomic_add_f64(&d.scal[SC_XNORM2], b3);
+    double* sc = SCAL_MINE(d);
+    atomic_add_f64(&sc[SC_GDOT], b0);
+    atomic_add_f64(&sc[SC_DHD], b1);
+    atomic_add_f64(&sc[SC_DNORM2], b2);
+    atomic_add_f64(&sc[SC_XNORM2], b3);
   }
 }
 
@@ -717,7 +833,7 @@ __global__ __launch_bounds__(256) void k_backsub(DeviceProblem d, double lam, do
     const int kb = d.lm_ptr[j], ke = d.lm_ptr[j + 1];
     double t[3] = {0, 0, 0};
     for (int k = kb + lane; k < ke; k += G) {
-      const int f = d.cam2free[d.o_cam[k]];
+      const int f = d.o_free[k];
       if (f < 0) continue;
       double dl[6];
 #pragma unroll
@@ -753,10 +869,11 @@ __global__ __launch_bounds__(256) void k_backsub(DeviceProblem d, double lam, do
   const double b0 = block_sum_256(gd, red), b1 = block_sum_256(dhd, red), b2 = block_sum_256(dn, red),
                b3 = block_sum_256(xn, red);
   if (threadIdx.x == 0) {
-    atomic_add_f64(&d.scal[SC_GDOT], b0);
-    atomic_add_f64(&d.scal[SC_DHD], b1);
-    atomic_add_f64(&d.scal[SC_DNORM2], b2);
-    atomic_add_f64(&d.scal[SC_XNORM2], b3);
+    double* sc = SCAL_MINE(d);
+    atomic_add_f64(&sc[SC_GDOT], b0);
+    atomic_add_f64(&sc[SC_DHD], b1);
+    atomic_add_f64(&sc[SC_DNORM2], b2);
+    atomic_add_f64(&sc[SC_XNORM2], b3);
   }
 }
 

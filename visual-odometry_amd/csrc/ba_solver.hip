@@ -166,6 +166,11 @@ int env_int(const char* name, int dflt) {
   return (s && *s) ? atoi(s) : dflt;
 }
 
+constexpr size_t SCAL_BYTES = (size_t)SCAL_SLABS * SC_COUNT * sizeof(double);
+
+// read back every copy of the scalar block and fold them into copy 0 (sum; max for SC_GINF)
+int fetch_scalars(ba_handle* h);
+
 inline int grid_for(long items, int block = 256) { return (int)std::max<long>(1, (items + block - 1) / block); }
 
 // ---------------------------------------------------------------------------------------------- launches
@@ -173,12 +178,12 @@ void launch_linearize(ba_handle* h, const double* poses, const double* pts) {
   const DeviceProblem& d = h->d;
   const long groups = (d.L_obs + h->lpg_lin - 1) / h->lpg_lin;
   const int G = h->g_lin;
-  const int grid = grid_for(groups * G);
+  const int grid = grid_for(groups * G, 64);
   switch (G) {
-    case 8: k_linearize<8><<<grid, 256, 0, h->stream>>>(d, poses, pts, h->lpg_lin); break;
-    case 16: k_linearize<16><<<grid, 256, 0, h->stream>>>(d, poses, pts, h->lpg_lin); break;
-    case 32: k_linearize<32><<<grid, 256, 0, h->stream>>>(d, poses, pts, h->lpg_lin); break;
-    default: k_linearize<64><<<grid, 256, 0, h->stream>>>(d, poses, pts, h->lpg_lin); break;
+    case 8: k_linearize<8><<<grid, 64, 0, h->stream>>>(d, poses, pts, h->lpg_lin); break;
+    case 16: k_linearize<16><<<grid, 64, 0, h->stream>>>(d, poses, pts, h->lpg_lin); break;
+    case 32: k_linearize<32><<<grid, 64, 0, h->stream>>>(d, poses, pts, h->lpg_lin); break;
+    default: k_linearize<64><<<grid, 64, 0, h->stream>>>(d, poses, pts, h->lpg_lin); break;
   }
 }
 
@@ -200,13 +205,13 @@ void launch_schur(ba_handle* h, double lam) {
   const DeviceProblem& d = h->d;
   const long groups = (d.L_obs + h->lpg_schur - 1) / h->lpg_schur;
   const int G = h->g_schur;
-  const int grid = grid_for(groups * G);
+  const int grid = grid_for(groups * G, 64);
   const double md = h->opt.min_diag;
   switch (G) {
-    case 8: k_schur<8><<<grid, 256, 0, h->stream>>>(d, lam, md, h->lpg_schur); break;
-    case 16: k_schur<16><<<grid, 256, 0, h->stream>>>(d, lam, md, h->lpg_schur); break;
-    case 32: k_schur<32><<<grid, 256, 0, h->stream>>>(d, lam, md, h->lpg_schur); break;
-    default: k_schur<64><<<grid, 256, 0, h->stream>>>(d, lam, md, h->lpg_schur); break;
+    case 8: k_schur<8><<<grid, 64, 0, h->stream>>>(d, lam, md, h->lpg_schur); break;
+    case 16: k_schur<16><<<grid, 64, 0, h->stream>>>(d, lam, md, h->lpg_schur); break;
+    case 32: k_schur<32><<<grid, 64, 0, h->stream>>>(d, lam, md, h->lpg_schur); break;
+    default: k_schur<64><<<grid, 64, 0, h->stream>>>(d, lam, md, h->lpg_schur); break;
   }
 }
 
@@ -218,7 +223,7 @@ void launch_cost(ba_handle* h, const double* poses, const double* pts, int cost_
 
 // linearise at (poses, pts): zero accumulators, blocks U V W gc gp, cost into scal[SC_COST]
 int do_linearize(ba_handle* h, const double* poses, const double* pts) {
-  HIP_TRY(h, hipMemsetAsync(h->d.scal, 0, SC_COUNT * sizeof(double), h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d.scal, 0, SCAL_BYTES, h->stream));
   {
     KSpan t(h, KT_OTHER, 1);
     HIP_TRY(h, hipMemsetAsync(h->d.Ugc_slab, 0, (size_t)h->d.nslab_u * h->C * 27 * sizeof(double), h->stream));
@@ -229,7 +234,7 @@ int do_linearize(ba_handle* h, const double* poses, const double* pts) {
   }
   {
     KSpan t(h, KT_OTHER, 1);
-    k_reduce_U<<<grid_for(27L * h->C), 256, 0, h->stream>>>(h->d);
+    k_reduce_U<<<grid_for(27L * h->C, 16), 256, 0, h->stream>>>(h->d);
   }
   return BA_OK;
 }
@@ -252,12 +257,12 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
   }
   const double tol2 = o.pcg_tol * o.pcg_tol;
   if (h->small_solve) {
-    KSpan t(h, KT_PCG, 1);
-    if (h->small_cached)
-      k_solve_small<SMALL_CACHED_ROWS><<<1, SMALL_THREADS, h->small_lds, h->stream>>>(d, lam, o.min_diag, tol2,
-                                                                                       o.pcg_max_iter);
+    KSpan t(h, KT_PCG, 2);
+    k_block_precond<<<grid_for(d.Cf, 64), 64, 0, h->stream>>>(d, lam, o.min_diag);
+    if (d.nu <= SMALL_THREADS)
+      k_solve_small<1><<<1, SMALL_THREADS, h->small_lds, h->stream>>>(d, lam, o.min_diag, tol2, o.pcg_max_iter);
     else
-      k_solve_small<0><<<1, SMALL_THREADS, h->small_lds, h->stream>>>(d, lam, o.min_diag, tol2, o.pcg_max_iter);
+      k_solve_small<2><<<1, SMALL_THREADS, h->small_lds, h->stream>>>(d, lam, o.min_diag, tol2, o.pcg_max_iter);
     *pcg_iters = -1;  // read from scal after the trial readback
     return BA_OK;
   }
@@ -307,8 +312,19 @@ int do_trial(ba_handle* h, double lam, const double* poses, const double* pts, d
     KSpan t(h, KT_COST);
     launch_cost(h, poses_t, pts_t, SC_COST_T, SC_NBEHIND_T, nullptr);
   }
-  HIP_TRY(h, hipMemcpyAsync(h->scal_host, d.scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  return fetch_scalars(h);
+}
+
+int fetch_scalars(ba_handle* h) {
+  HIP_TRY(h, hipMemcpyAsync(h->scal_host, h->d.scal, SCAL_BYTES, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  double* s0 = h->scal_host;
+  for (int k = 1; k < SCAL_SLABS; ++k) {
+    const double* sk = s0 + (size_t)k * SC_COUNT;
+    for (int i = 0; i < SC_RZ; ++i) {
+      if (i == SC_GINF) s0[i] = std::max(s0[i], sk[i]); else s0[i] += sk[i];
+    }
+  }
   return BA_OK;
 }
 
@@ -382,7 +398,7 @@ int lm_solve(ba_handle* h, ba_report* rep) {
       if ((rc = do_linearize(h, poses, pts))) return rc;
       rep->linearizations++;
     } else {
-      HIP_TRY(h, hipMemsetAsync(d.scal, 0, SC_COUNT * sizeof(double), h->stream));
+      HIP_TRY(h, hipMemsetAsync(d.scal, 0, SCAL_BYTES, h->stream));
     }
     int pcg_it = 0;
     if ((rc = do_reduced_solve(h, lam, &pcg_it))) return rc;
@@ -507,7 +523,7 @@ int ba_create(const ba_options* opt, ba_handle** out) {
   if (dev >= ndev) { delete h; return BA_ERR_INVALID; }
   h->device = dev;
   if (hipSetDevice(dev) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess ||
-      hipHostMalloc((void**)&h->scal_host, SC_COUNT * sizeof(double)) != hipSuccess) {
+      hipHostMalloc((void**)&h->scal_host, SCAL_BYTES) != hipSuccess) {
     delete h;
     return BA_ERR_DEVICE;
   }
@@ -621,6 +637,8 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
     }
   }
   h->obs_src = o_src;
+  std::vector<int> o_free(n);
+  for (int k = 0; k < n; ++k) o_free[k] = h->cam2free[o_cam[k]];
 
   // ---- block pattern of the reduced camera system (upper triangle over free cameras)
   std::vector<int64_t> keys;
@@ -674,6 +692,12 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
   }
   h->urow_ptr = urow_ptr;
   h->ucol = ucol;
+  std::vector<int> sm_slot(nu);
+  std::iota(sm_slot.begin(), sm_slot.end(), 0);
+  std::sort(sm_slot.begin(), sm_slot.end(), [&](int a, int b) {
+    const int da = ucol[a] - urow[a], db = ucol[b] - urow[b];
+    return da != db ? da < db : urow[a] < urow[b];
+  });
 
   // ---- launch geometry
   {
@@ -685,7 +709,7 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
     const int len90 = std::max(1, tmp[q]);
     h->g_lin = env_int("BA_G_LIN", pow2_at_least(len90, 8, 64));
     h->g_schur = env_int("BA_G_SCHUR", pow2_at_least(len90 * (len90 + 1) / 2, 8, 64));
-    const long target_waves = 256L * 8;  // ~8 waves per CU
+    const long target_waves = 256L * 4;  // ~4 waves per CU (run-length accumulation wants long ranges)
     const long groups_lin = target_waves * (64 / h->g_lin), groups_schur = target_waves * (64 / h->g_schur);
     h->lpg_lin = env_int("BA_LPG_LIN", (int)std::max<long>(1, (L_obs + groups_lin - 1) / groups_lin));
     h->lpg_schur = env_int("BA_LPG_SCHUR", (int)std::max<long>(1, (L_obs + groups_schur - 1) / groups_schur));
@@ -696,19 +720,18 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
     const size_t u_bytes = (size_t)C * 27 * sizeof(double);
     const size_t s_bytes = ((size_t)nu * 36 + (size_t)6 * Cf) * sizeof(double);
     h->d.nslab_u = env_int("BA_NSLAB_U", (int)std::min<size_t>(256, std::max<size_t>(1, ((size_t)8 << 20) / u_bytes)));
-    h->d.nslab_s = env_int("BA_NSLAB_S", (int)std::min<size_t>(64, std::max<size_t>(1, ((size_t)32 << 20) / s_bytes)));
+    h->d.nslab_s = env_int("BA_NSLAB_S", (int)std::min<size_t>(16, std::max<size_t>(1, ((size_t)32 << 20) / s_bytes)));
     h->d.s_slab_stride = (long)nu * 36 + 6L * Cf;
   }
   // one-workgroup reduced solve for small camera systems (vectors + preconditioner in LDS)
   {
-    h->small_lds = ((size_t)5 * 6 * Cf + (size_t)36 * Cf + 32) * sizeof(double);
-    h->small_solve = env_int("BA_SMALL_SOLVE", 1) && Cf <= 256 && h->small_lds <= 160 * 1024 &&
-                     h->opt.linear_solver != BA_SOLVER_DENSE_CHOLESKY;
-    h->small_cached = env_int("BA_SMALL_CACHED", 1) != 0;
+    h->small_lds = ((size_t)4 * 6 * Cf + (size_t)36 * Cf + 16) * sizeof(double);
+    h->small_solve = env_int("BA_SMALL_SOLVE", 1) && 6 * Cf <= SMALL_VPT * SMALL_THREADS &&
+                     nu <= 4 * SMALL_THREADS && h->small_lds <= 160 * 1024;
     if (h->small_solve && h->small_lds > 64 * 1024) {
-      HIP_TRY(h, hipFuncSetAttribute((const void*)k_solve_small<SMALL_CACHED_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      HIP_TRY(h, hipFuncSetAttribute((const void*)k_solve_small<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)h->small_lds));
-      HIP_TRY(h, hipFuncSetAttribute((const void*)k_solve_small<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      HIP_TRY(h, hipFuncSetAttribute((const void*)k_solve_small<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)h->small_lds));
     }
   }
@@ -723,12 +746,13 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
   int rc;
   if ((rc = dev_upload(h, &d.o_cam, o_cam)) || (rc = dev_upload(h, &d.o_u, o_u)) || (rc = dev_upload(h, &d.o_v, o_v)) ||
       (rc = dev_upload(h, &d.o_src, o_src)) || (rc = dev_upload(h, &d.o_lm, o_lm)) ||
+      (rc = dev_upload(h, &d.o_free, o_free)) ||
       (rc = dev_upload(h, &d.lm_ptr, lm_ptr)) || (rc = dev_upload(h, &d.cam2free, h->cam2free)) ||
       (rc = dev_upload(h, &d.free2cam, h->free2cam)) || (rc = dev_upload(h, &d.urow_ptr, urow_ptr)) ||
       (rc = dev_upload(h, &d.ucol, ucol)) || (rc = dev_upload(h, &d.urow, urow)) ||
       (rc = dev_upload(h, &d.diag_slot, diag_slot)) || (rc = dev_upload(h, &d.low_of, low_of)) ||
       (rc = dev_upload(h, &d.brow_ptr, brow_ptr)) || (rc = dev_upload(h, &d.bcol, bcol)) ||
-      (rc = dev_upload(h, &d.bslot, bslot)))
+      (rc = dev_upload(h, &d.bslot, bslot)) || (rc = dev_upload(h, &d.sm_slot, sm_slot)))
     return rc;
   if ((rc = dev_alloc(h, &d.W, (size_t)18 * n)) || (rc = dev_alloc(h, &d.V, (size_t)6 * L)) ||
       (rc = dev_alloc(h, &d.gp, (size_t)3 * L)) || (rc = dev_alloc(h, &d.Ugc, (size_t)27 * C)) ||
@@ -738,7 +762,7 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
       (rc = dev_alloc(h, &d.Udiag, (size_t)6 * Cf)) || (rc = dev_alloc(h, &d.Minv, (size_t)36 * Cf)) ||
       (rc = dev_alloc(h, &d.dc, (size_t)6 * Cf)) || (rc = dev_alloc(h, &d.r, (size_t)6 * Cf)) ||
       (rc = dev_alloc(h, &d.z, (size_t)6 * Cf)) || (rc = dev_alloc(h, &d.p, (size_t)6 * Cf)) ||
-      (rc = dev_alloc(h, &d.q, (size_t)6 * Cf)) || (rc = dev_alloc(h, &d.scal, (size_t)SC_COUNT)) ||
+      (rc = dev_alloc(h, &d.q, (size_t)6 * Cf)) || (rc = dev_alloc(h, &d.scal, (size_t)SC_COUNT * SCAL_SLABS)) ||
       (rc = dev_alloc(h, &h->poses_cur, (size_t)7 * C)) || (rc = dev_alloc(h, &h->poses_trial, (size_t)7 * C)) ||
       (rc = dev_alloc(h, &h->poses_init, (size_t)7 * C)) || (rc = dev_alloc(h, &h->pts_cur, (size_t)3 * L)) ||
       (rc = dev_alloc(h, &h->pts_trial, (size_t)3 * L)) || (rc = dev_alloc(h, &h->pts_init, (size_t)3 * L)))
@@ -800,12 +824,11 @@ int ba_evaluate(ba_handle* h, const double* poses, const double* points, double*
   h->has_estimate = false;  // the trial buffers were clobbered
   double* d_res = nullptr;
   if (residuals) HIP_TRY(h, hipMalloc((void**)&d_res, (size_t)2 * h->n * sizeof(double)));
-  HIP_TRY(h, hipMemsetAsync(h->d.scal, 0, SC_COUNT * sizeof(double), h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d.scal, 0, SCAL_BYTES, h->stream));
   launch_cost(h, h->poses_trial, h->pts_trial, SC_COST_T, SC_NBEHIND_T, d_res);
-  HIP_TRY(h, hipMemcpyAsync(h->scal_host, h->d.scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (residuals)
     HIP_TRY(h, hipMemcpyAsync(residuals, d_res, (size_t)2 * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if ((rc = fetch_scalars(h))) return rc;
   if (d_res) (void)hipFree(d_res);
   if (cost) *cost = h->scal_host[SC_COST_T];
   if (n_behind) *n_behind = (int32_t)h->scal_host[SC_NBEHIND_T];
@@ -886,8 +909,17 @@ int ba_debug_linearization(ba_handle* h, const double* poses, const double* poin
       for (int e = 0; e < 18; ++e) W[18 * (size_t)h->obs_src[k] + e] = t[(size_t)e * n + k];
   }
   if (S) {
-    std::vector<int> urow, low_of;
     if ((rc = fetch(t, d.S, (size_t)36 * (d.nu + d.nl)))) return rc;
+    if (h->small_solve) {  // the one-workgroup solve applies the damping on the fly; add it for the export
+      std::vector<double> ud;
+      if ((rc = fetch(ud, d.Udiag, (size_t)6 * Cf))) return rc;
+      for (int f = 0; f < Cf; ++f) {
+        int sl = -1;
+        for (int s2 = h->urow_ptr[f]; s2 < h->urow_ptr[f + 1]; ++s2)
+          if (h->ucol[s2] == f) sl = s2;
+        for (int i = 0; i < 6; ++i) t[36 * (size_t)sl + 7 * i] += lambda * std::max(ud[6 * (size_t)f + i], h->opt.min_diag);
+      }
+    }
     const size_t N = (size_t)6 * C;
     std::fill(S, S + N * N, 0.0);
     for (int c = 0; c < C; ++c)

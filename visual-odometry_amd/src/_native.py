@@ -13,7 +13,8 @@ import numpy as np
 from .validation_error import ProcessingError, ValidationError
 
 BA_HISTORY = 128
-_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib", "libba_amd.so")
+_LIB_PATH = os.environ.get("BA_AMD_LIB") or os.path.join(
+    os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib", "libba_amd.so")
 
 STATUS_NAMES = {0: "max_iters", 1: "gtol", 2: "ftol", 3: "xtol"}
 
