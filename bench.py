@@ -7,8 +7,9 @@ A "step" is one complete solve (ba_solve_resident) of the synthetic ring scene f
 guess, with observations, poses and points already resident in HBM; value = observations x LM
 iterations summed over the K timed steps / wall time of those steps (max over ranks).  N = 1 runs
 BASELINE.json configs[1] (50 cameras x 20k landmarks x 200k observations).  For N > 1 (launched by
-torch.distributed.run, one rank per GPU) every rank solves its own replica-sized shard: see
-DESIGN.md "Multi-GPU".  Rank 0 prints ONE JSON line.
+torch.distributed.run, one rank per GPU) the N GPUs solve one scene with N times the landmarks and
+observations, sharded by landmark track (weak scaling; DESIGN.md "Multi-GPU").  Rank 0 prints ONE
+JSON line.
 """
 
 import argparse
@@ -85,15 +86,30 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import scenes
+    import sharding
     from src import _native
 
-    C, L, d = WORKLOADS[args.workload]
-    scene = scenes.ring_scene(C, L, d, seed=rank)  # weak scaling: one replica-sized scene per rank
-    nobs = len(scene["obs_cam"])
-
+    # Weak scaling: N GPUs solve ONE scene N times the size (same cameras, N x the landmarks and
+    # observations), sharded by landmark track; one RCCL all-reduce of the reduced system per solve.
+    C, L1, d = WORKLOADS[args.workload]
+    L = L1 * world
+    scene = scenes.ring_scene(C, L, d, seed=0)
     solver = _native.Solver(device=local_rank, profile_kernels=0 if args.no_kernel_events else 1)
-    solver.set_problem(C, L, scene["obs_cam"], scene["obs_pt"], scene["obs_uv"], scene["intr"])
-    solver.upload_guess(scene["poses_guess"], scene["points_guess"])
+    if world > 1:
+        uid = [_native.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        solver.comm_init(rank, world, uid[0])
+        sh, _ = sharding.shard_arrays(scene["obs_cam"], scene["obs_pt"], scene["obs_uv"], scene["points_guess"],
+                                      rank, world)
+        solver.set_problem(C, len(sh["points"]), sh["obs_cam"], sh["obs_pt"], sh["obs_uv"], scene["intr"])
+        solver.upload_guess(scene["poses_guess"], sh["points"])
+        nobs = len(sh["obs_cam"])
+        L_local = len(sh["points"])
+    else:
+        solver.set_problem(C, L, scene["obs_cam"], scene["obs_pt"], scene["obs_uv"], scene["intr"])
+        solver.upload_guess(scene["poses_guess"], scene["points_guess"])
+        nobs = len(scene["obs_cam"])
+        L_local = L
 
     def barrier():
         if dist is not None:
@@ -131,14 +147,14 @@ def main():
         if big:
             dom = max(big, key=lambda k: big[k][0])
             avg_ms = big[dom][0] / big[dom][1]
-            bytes_launch = algorithmic_bytes(dom, nobs, L, C)
+            bytes_launch = algorithmic_bytes(dom, nobs, L_local, C)
             ach = bytes_launch / (avg_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": avg_ms,
                         "algorithmic_bytes_per_launch": bytes_launch,
                         "per_kernel": {k: {"total_ms": v[0], "launches": v[1],
                                            "avg_us": 1e3 * v[0] / max(v[1], 1),
-                                           "GBps": (algorithmic_bytes(k, nobs, L, C) / (v[0] / v[1] * 1e-3) / 1e9)
+                                           "GBps": (algorithmic_bytes(k, nobs, L_local, C) / (v[0] / v[1] * 1e-3) / 1e9)
                                            if k in big else None}
                                        for k, v in ktimes.items()}}
         out = {
@@ -146,9 +162,11 @@ def main():
             "unit": "observations*iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: ring scene {C} cameras x {L} landmarks x {nobs} observations "
+            "config": {"workload": f"{args.workload}: ring scene {C} cameras x {L1} landmarks x {L1 * d} observations "
                                    f"(track length {d}), sigma_px 0.5, per GPU",
-                       "cameras": C, "landmarks": L, "observations": nobs, "parallelism": f"replica x{world}"},
+                       "cameras": C, "landmarks_total": L, "observations_total": L * d,
+                       "parallelism": f"landmark-sharded x{world}, RCCL all-reduce of the reduced camera system"
+                       if world > 1 else "single GPU"},
             "time_to_converge_ms": rep["solve_ms"], "lm_iterations": rep["iterations"],
             "pcg_iterations": rep["pcg_iters"], "final_cost": rep["cost"], "status": rep["status_name"],
             "rms_reproj_px": rep["rms_reproj"], "setup_ms": rep["setup_ms"],

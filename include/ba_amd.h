@@ -167,6 +167,19 @@ int ba_debug_linearization(ba_handle* h, const double* poses, const double* poin
 #define BA_KERNEL_CLASSES 6
 int ba_get_kernel_times(ba_handle* h, double* total_ms, int32_t* launches);
 
+/* Multi-GPU (one process per GPU, landmark-sharded; no reference counterpart -- the reference is one
+ * Python thread).  Rank 0 calls ba_comm_unique_id and ships the 128 bytes to the other ranks by any
+ * means (bench.py: torch.distributed); every rank then calls ba_comm_init on its handle BEFORE
+ * ba_set_problem.  Afterwards each rank describes ITS shard to ba_set_problem: all C cameras, its own
+ * landmarks and their observations (obs_pt indexes the local landmark array).  Poses are replicated
+ * (every rank passes and receives all of them); points are rank-local.  ba_solve* then runs the same
+ * iteration on every rank with one RCCL all-reduce of [partial S | reduced rhs | U, gc] per
+ * linear solve, a broadcast of the camera step and one all-reduce of the scalar statistics; report
+ * fields are global.  ba_evaluate / ba_jacobian_blocks stay rank-local.  With world == 1 the same code
+ * path runs with single-rank collectives. */
+int ba_comm_unique_id(char* id128);
+int ba_comm_init(ba_handle* h, int32_t rank, int32_t world, const char* id128);
+
 /* Number of stored 6x6 blocks of the reduced camera system (upper triangle incl. diagonal). */
 int ba_schur_block_count(const ba_handle* h, int64_t* n_upper_blocks);
 

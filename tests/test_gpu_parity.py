@@ -220,3 +220,42 @@ def test_error_mapping(golden):
             s.evaluate(ident, flat)
         with pytest.raises(ProcessingError):
             s.solve(ident, flat)
+
+
+def test_single_rank_communicator_path_matches_plain_solve():
+    """The multi-GPU code path (RCCL all-reduce of [S | rhs | U,gc], broadcast of the camera step,
+    all-reduce of the statistics) with a one-rank communicator must reproduce the plain solve."""
+    sc = scenes.ring_scene(50, 2000, 10)
+    C, L = len(sc["poses_guess"]), len(sc["points_guess"])
+    with _native.Solver() as s:
+        s.set_problem(C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+        P0, X0, rep0 = s.solve(sc["poses_guess"], sc["points_guess"])
+    with _native.Solver() as s:
+        s.comm_init(0, 1, _native.comm_unique_id())
+        s.set_problem(C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+        P1, X1, rep1 = s.solve(sc["poses_guess"], sc["points_guess"])
+    assert rep1["iterations"] == rep0["iterations"] and rep1["status"] == rep0["status"]
+    assert abs(rep1["cost"] - rep0["cost"]) <= 1e-10 * rep0["cost"]
+    assert abs(rep1["cost0"] - rep0["cost0"]) <= 1e-12 * rep0["cost0"]
+    assert rep1["nobs"] == len(sc["obs_cam"])
+    np.testing.assert_allclose(P1, P0, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(X1, X0, rtol=0, atol=1e-8)
+
+
+def test_large_system_path_matches_small_path():
+    """The multi-kernel PCG path (used when the camera system does not fit one workgroup) against the
+    one-workgroup path on the same scene."""
+    import os
+    sc = scenes.ring_scene(50, 2000, 10)
+    C, L = len(sc["poses_guess"]), len(sc["points_guess"])
+    out = []
+    for small in ("1", "0"):
+        os.environ["BA_SMALL_SOLVE"] = small
+        try:
+            with _native.Solver(pcg_tol=1e-6) as s:
+                s.set_problem(C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+                out.append(s.solve(sc["poses_guess"], sc["points_guess"]))
+        finally:
+            os.environ.pop("BA_SMALL_SOLVE", None)
+    assert abs(out[0][2]["cost"] - out[1][2]["cost"]) <= 1e-9 * out[0][2]["cost"]
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=0, atol=1e-6)

@@ -18,7 +18,10 @@
 enum ScalarSlot {
   SC_COST = 0, SC_COST_T, SC_GDOT, SC_DHD, SC_DNORM2, SC_XNORM2, SC_GINF, SC_NBEHIND, SC_NBEHIND_T, SC_BADV,
   SC_ZEROZ, SC_NONFINITE,
-  SC_RZ = 16, SC_RZ0, SC_PQ, SC_RZNEW, SC_DONE, SC_PCGIT,
+  // camera part of the step statistics: computed from replicated data, identical on every rank
+  SC_GDOT_C, SC_DHD_C, SC_DNORM2_C, SC_XNORM2_C, SC_GINF_C,
+  SC_NSUM = 20,  // slots [0, SC_NSUM) are folded over the privatised copies (and over ranks)
+  SC_RZ = 24, SC_RZ0, SC_PQ, SC_RZNEW, SC_DONE, SC_PCGIT,
   SC_COUNT = 32
 };
 // Scalar accumulators are privatised too: block b adds into copy (b mod SCAL_SLABS); the host sums
@@ -48,7 +51,9 @@ struct DeviceProblem {
   int nu, nl, nb;
   // state
   double* W; double* V; double* gp; double* Ugc;
-  double* S; double* rhs; double* Udiag; double* Minv;
+  // S (upper blocks), rhs and Ugc are consecutive in ONE allocation [nu*36 | 6*Cf | 27*C]: the buffer
+  // that the multi-GPU all-reduce sums (ba_solver.hip).  Ugc_part is this GPU's partial U / gc.
+  double* S; double* rhs; double* Ugc_part; double* Minv;
   // privatised accumulation slabs (atomics from different groups land in different copies; a reduce
   // kernel sums the copies): Ugc_slab [nslab_u][C][27]; S_slab [nslab_s][nu*36 + 6*Cf] (S upper | rhs)
   double* Ugc_slab; double* S_slab;
@@ -254,36 +259,41 @@ __global__ __launch_bounds__(256) void k_reduce_U(DeviceProblem d) {
     double tsum = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) tsum += part[threadIdx.x + 16 * k];
-    d.Ugc[t] = tsum;
-    const int cam = (int)(t / 27), e = (int)(t - 27L * cam);
-    if (e >= 21 && d.cam2free[cam] >= 0) gmax = fabs(tsum);
+    d.Ugc_part[t] = tsum;
   }
-  const double bg = block_max_256(gmax, red);
-  if (threadIdx.x == 0 && bg > 0.0) atomic_max_nonneg(&SCAL_MINE(d)[SC_GINF], bg);
+  (void)red;
+  (void)gmax;
 }
 
-// k_reduce_S: S (upper blocks) = sum of the slabs (+ U on the diagonal blocks), rhs = gc + sum of
-// the slabs' rhs part, Udiag = diag(U).  One thread per entry of [nu*36 | 6*Cf].
+// k_reduce_S: S (upper blocks) = sum of the slabs (+ partial U on the diagonal blocks), rhs = partial gc
+// + sum of the slabs' rhs part, Ugc = partial U/gc.  One thread per entry of [nu*36 | 6*Cf | 27*C].
 __global__ __launch_bounds__(256) void k_reduce_S(DeviceProblem d) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long nS = (long)d.nu * 36;
-  if (t >= nS + 6L * d.Cf) return;
+  const long nS = (long)d.nu * 36, nR = 6L * d.Cf, nU = 27L * d.C;
+  if (t >= nS + nR + nU) return;
+  if (t >= nS + nR) {  // this GPU's partial U / gc, into the buffer the all-reduce sums
+    d.Ugc[t - nS - nR] = d.Ugc_part[t - nS - nR];
+    return;
+  }
   double sum = 0.0;
   for (int k = 0; k < d.nslab_s; ++k) sum += d.S_slab[(long)k * d.s_slab_stride + t];
   if (t < nS) {
     const int s = (int)(t / 36), e = (int)(t - 36L * s);
     if (d.low_of[s] < 0) {
       const int f = d.urow[s], i = e / 6, c = e - 6 * i;
-      const double u = d.Ugc[(long)d.free2cam[f] * 27 + (i <= c ? sym6_index(i, c) : sym6_index(c, i))];
-      sum += u;
-      if (i == c) d.Udiag[6 * f + i] = u;
+      sum += d.Ugc_part[(long)d.free2cam[f] * 27 + (i <= c ? sym6_index(i, c) : sym6_index(c, i))];
     }
     d.S[t] = sum;
   } else {
     const long r = t - nS;
     const int f = (int)(r / 6), i = (int)(r - 6L * f);
-    d.rhs[r] = sum + d.Ugc[(long)d.free2cam[f] * 27 + 21 + i];
+    d.rhs[r] = sum + d.Ugc_part[(long)d.free2cam[f] * 27 + 21 + i];
   }
+}
+
+// diagonal entry i of U for free camera f (Marquardt scaling), from the (all-reduced) Ugc
+__device__ __forceinline__ double u_diag(const DeviceProblem& d, int f, int i) {
+  return d.Ugc[(long)d.free2cam[f] * 27 + sym6_index(i, i)];
 }
 
 // Find the upper-triangle slot of block (fa, fb), fa <= fb, by binary search in row fa.
@@ -455,7 +465,7 @@ __global__ __launch_bounds__(256) void k_damp_mirror(DeviceProblem d, double lam
 #pragma unroll
     for (int i = 0; i < 36; ++i) A[i] = Sb[i];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) A[7 * i] += lam * fmax(d.Udiag[6 * f + i], min_diag);
+    for (int i = 0; i < 6; ++i) A[7 * i] += lam * fmax(u_diag(d, f, i), min_diag);
 #pragma unroll
     for (int i = 0; i < 36; ++i) Sb[i] = A[i];
     if (!spd_inverse6(A)) atomic_add_f64(&d.scal[SC_BADV], 1.0);
@@ -582,7 +592,7 @@ __global__ __launch_bounds__(64) void k_block_precond(DeviceProblem d, double la
 #pragma unroll
   for (int i = 0; i < 36; ++i) A[i] = Sd[i];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) A[7 * i] += lam * fmax(d.Udiag[6 * f + i], min_diag);
+  for (int i = 0; i < 6; ++i) A[7 * i] += lam * fmax(u_diag(d, f, i), min_diag);
   if (!spd_inverse6(A)) atomic_add_f64(&d.scal[SC_BADV], 1.0);
 #pragma unroll
   for (int i = 0; i < 36; ++i) d.Minv[(long)f * 36 + i] = A[i];
@@ -637,7 +647,7 @@ __device__ __forceinline__ void small_load_block(const DeviceProblem& d, int t, 
   for (int e = 0; e < 36; ++e) B[e] = d.S[(long)s * 36 + e];
   if (i == j) {
 #pragma unroll
-    for (int e = 0; e < 6; ++e) B[7 * e] += lam * fmax(d.Udiag[6 * i + e], min_diag);
+    for (int e = 0; e < 6; ++e) B[7 * e] += lam * fmax(u_diag(d, i, e), min_diag);
   }
 }
 
@@ -769,7 +779,7 @@ __global__ __launch_bounds__(256) void k_pose_update(DeviceProblem d, const doub
                                                      double* __restrict__ poses_t) {
   __shared__ double red[4];
   const int cam = blockIdx.x * blockDim.x + threadIdx.x;
-  double gd = 0.0, dhd = 0.0, dn = 0.0, xn = 0.0;
+  double gd = 0.0, dhd = 0.0, dn = 0.0, xn = 0.0, gmax = 0.0;
   if (cam < d.C) {
     const int f = d.cam2free[cam];
     const double* ps = poses + 7 * cam;
@@ -785,6 +795,7 @@ __global__ __launch_bounds__(256) void k_pose_update(DeviceProblem d, const doub
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         gd += u[21 + i] * dl[i];
+        gmax = fmax(gmax, fabs(u[21 + i]));
         dn += dl[i] * dl[i];
 #pragma unroll
         for (int c = 0; c < 6; ++c) dhd += dl[i] * u[i <= c ? sym6_index(i, c) : sym6_index(c, i)] * dl[c];
@@ -803,13 +814,14 @@ __global__ __launch_bounds__(256) void k_pose_update(DeviceProblem d, const doub
     }
   }
   const double b0 = block_sum_256(gd, red), b1 = block_sum_256(dhd, red), b2 = block_sum_256(dn, red),
-               b3 = block_sum_256(xn, red);
+               b3 = block_sum_256(xn, red), b4 = block_max_256(gmax, red);
   if (threadIdx.x == 0) {
     double* sc = SCAL_MINE(d);
-    atomic_add_f64(&sc[SC_GDOT], b0);
-    atomic_add_f64(&sc[SC_DHD], b1);
-    atomic_add_f64(&sc[SC_DNORM2], b2);
-    atomic_add_f64(&sc[SC_XNORM2], b3);
+    atomic_add_f64(&sc[SC_GDOT_C], b0);
+    atomic_add_f64(&sc[SC_DHD_C], b1);
+    atomic_add_f64(&sc[SC_DNORM2_C], b2);
+    atomic_add_f64(&sc[SC_XNORM2_C], b3);
+    atomic_max_nonneg(&sc[SC_GINF_C], b4);
   }
 }
 
@@ -881,4 +893,24 @@ __global__ __launch_bounds__(256) void k_backsub(DeviceProblem d, double lam, do
 __global__ void k_copy_tail(const double* __restrict__ src, double* __restrict__ dst, long begin, long end) {
   for (long i = begin + (long)blockIdx.x * blockDim.x + threadIdx.x; i < end; i += (long)gridDim.x * blockDim.x)
     dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_fold_scalars (multi-GPU only): fold the privatised scalar copies into out[0, SC_NSUM) (sum; max
+// for the two inf-norm slots) so that one small all-reduce can combine the ranks.  Slots whose value
+// is replicated (camera part) are zeroed on every rank but the root, so that the sum over ranks is
+// the root's value.  out[SC_COUNT] receives the point-gradient inf-norm for the MAX all-reduce.
+__global__ __launch_bounds__(64) void k_fold_scalars(DeviceProblem d, double* __restrict__ out, int is_root) {
+  const int i = threadIdx.x;
+  if (i >= SC_NSUM) return;
+  const bool is_max = (i == SC_GINF || i == SC_GINF_C);
+  double v = 0.0;
+  for (int k = 0; k < SCAL_SLABS; ++k) {
+    const double x = d.scal[(size_t)k * SC_COUNT + i];
+    v = is_max ? fmax(v, x) : v + x;
+  }
+  const bool replicated = (i == SC_GDOT_C || i == SC_DHD_C || i == SC_DNORM2_C || i == SC_XNORM2_C || i == SC_GINF_C);
+  if (replicated && !is_root) v = 0.0;
+  if (i == SC_GINF) { out[SC_COUNT] = v; v = 0.0; }
+  out[i] = v;
 }

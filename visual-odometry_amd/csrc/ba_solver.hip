@@ -15,6 +15,9 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl.so is dlopen()ed by ba_comm_init
+
 namespace {
 
 using clk = std::chrono::steady_clock;
@@ -22,10 +25,38 @@ inline double ms_since(clk::time_point t0) {
   return std::chrono::duration<double, std::milli>(clk::now() - t0).count();
 }
 
-struct DevBuf {  // owning device allocation
-  void* p = nullptr;
-  size_t bytes = 0;
+// RCCL entry points, resolved at run time so that the single-GPU path has no RCCL dependency.
+struct Rccl {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
+
+Rccl* rccl_load() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return r.lib ? &r : nullptr;
+  tried = true;
+  void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) return nullptr;
+#define RCCL_SYM(name)                                                        \
+  r.name = reinterpret_cast<decltype(r.name)>(dlsym(lib, "nccl" #name));      \
+  if (!r.name) return nullptr;
+  RCCL_SYM(GetUniqueId) RCCL_SYM(CommInitRank) RCCL_SYM(CommDestroy) RCCL_SYM(AllReduce) RCCL_SYM(Broadcast)
+  RCCL_SYM(AllGather) RCCL_SYM(GroupStart) RCCL_SYM(GroupEnd) RCCL_SYM(GetErrorString)
+#undef RCCL_SYM
+  r.lib = lib;
+  return &r;
+}
 
 }  // namespace
 
@@ -63,6 +94,13 @@ struct ba_handle {
   std::vector<Span> spans;
   double ktime_ms[BA_KERNEL_CLASSES] = {0, 0, 0, 0, 0, 0};
   int kcount[BA_KERNEL_CLASSES] = {0, 0, 0, 0, 0, 0};
+
+  // multi-GPU: landmark-sharded ranks, one RCCL communicator (ba_comm_init)
+  Rccl* rccl = nullptr;
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+  double* scal_fold = nullptr;  // device [SC_COUNT + 1]: folded scalars + point-gradient inf-norm
+  long n_global = 0;            // observations over all ranks
 };
 
 namespace {
@@ -86,6 +124,12 @@ int fail(ba_handle* h, int code, const char* fmt, ...) {
   } while (0)
 
 enum { KT_LIN = 0, KT_SCHUR, KT_BACKSUB, KT_COST, KT_PCG, KT_OTHER };
+
+#define NCCL_TRY(h, expr)                                                                              \
+  do {                                                                                                 \
+    ncclResult_t r_ = (expr);                                                                          \
+    if (r_ != ncclSuccess) return fail(h, BA_ERR_DEVICE, "%s failed: %s", #expr, (h)->rccl->GetErrorString(r_)); \
+  } while (0)
 
 hipEvent_t next_event(ba_handle* h) {
   if (h->ev_used == h->ev_pool.size()) {
@@ -253,17 +297,25 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
   }
   {
     KSpan t(h, KT_OTHER, 1);
-    k_reduce_S<<<grid_for(d.s_slab_stride), 256, 0, h->stream>>>(d);
+    k_reduce_S<<<grid_for(d.s_slab_stride + 27L * d.C), 256, 0, h->stream>>>(d);
   }
+  const size_t red_count = (size_t)d.nu * 36 + (size_t)6 * d.Cf + (size_t)27 * d.C;
+  if (h->world > 1)  // the one exchange step of the path: partial S, reduced rhs, U / gc summed over the shards
+    NCCL_TRY(h, h->rccl->AllReduce(d.S, d.S, red_count, ncclDouble, ncclSum, h->comm, h->stream));
   const double tol2 = o.pcg_tol * o.pcg_tol;
   if (h->small_solve) {
-    KSpan t(h, KT_PCG, 2);
-    k_block_precond<<<grid_for(d.Cf, 64), 64, 0, h->stream>>>(d, lam, o.min_diag);
-    if (d.nu <= SMALL_THREADS)
-      k_solve_small<1><<<1, SMALL_THREADS, h->small_lds, h->stream>>>(d, lam, o.min_diag, tol2, o.pcg_max_iter);
-    else
-      k_solve_small<2><<<1, SMALL_THREADS, h->small_lds, h->stream>>>(d, lam, o.min_diag, tol2, o.pcg_max_iter);
+    {
+      KSpan t(h, KT_PCG, 2);
+      k_block_precond<<<grid_for(d.Cf, 64), 64, 0, h->stream>>>(d, lam, o.min_diag);
+      if (d.nu <= SMALL_THREADS)
+        k_solve_small<1><<<1, SMALL_THREADS, h->small_lds, h->stream>>>(d, lam, o.min_diag, tol2, o.pcg_max_iter);
+      else
+        k_solve_small<2><<<1, SMALL_THREADS, h->small_lds, h->stream>>>(d, lam, o.min_diag, tol2, o.pcg_max_iter);
+    }
     *pcg_iters = -1;  // read from scal after the trial readback
+    // every rank solved the same system; ship rank 0's step so that all replicas of the poses stay
+    // bit-identical (LDS atomics make the summation order, hence the last bits, rank-dependent)
+    if (h->world > 1) NCCL_TRY(h, h->rccl->Broadcast(d.dc, d.dc, (size_t)6 * d.Cf, ncclDouble, 0, h->comm, h->stream));
     return BA_OK;
   }
   {
@@ -288,12 +340,15 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
       }
     }
     launched += nb;
+    if (h->world > 1)  // all ranks must take the same number of PCG batches: follow rank 0's scalars
+      NCCL_TRY(h, h->rccl->Broadcast(d.scal + SC_RZ, d.scal + SC_RZ, 8, ncclDouble, 0, h->comm, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->scal_host + SC_RZ, d.scal + SC_RZ, 8 * sizeof(double), hipMemcpyDeviceToHost,
                               h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->scal_host[SC_DONE] != 0.0) break;
   }
   *pcg_iters = (int)h->scal_host[SC_PCGIT];
+  if (h->world > 1) NCCL_TRY(h, h->rccl->Broadcast(d.dc, d.dc, (size_t)6 * d.Cf, ncclDouble, 0, h->comm, h->stream));
   return BA_OK;
 }
 
@@ -316,13 +371,28 @@ int do_trial(ba_handle* h, double lam, const double* poses, const double* pts, d
 }
 
 int fetch_scalars(ba_handle* h) {
-  HIP_TRY(h, hipMemcpyAsync(h->scal_host, h->d.scal, SCAL_BYTES, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
   double* s0 = h->scal_host;
+  if (h->world > 1) {
+    // fold on the device, combine the ranks (sum; max for the point-gradient norm), read back
+    k_fold_scalars<<<1, 64, 0, h->stream>>>(h->d, h->scal_fold, h->rank == 0);
+    NCCL_TRY(h, h->rccl->GroupStart());
+    NCCL_TRY(h, h->rccl->AllReduce(h->scal_fold, h->scal_fold, SC_NSUM, ncclDouble, ncclSum, h->comm, h->stream));
+    NCCL_TRY(h, h->rccl->AllReduce(h->scal_fold + SC_COUNT, h->scal_fold + SC_COUNT, 1, ncclDouble, ncclMax, h->comm,
+                                   h->stream));
+    NCCL_TRY(h, h->rccl->GroupEnd());
+    HIP_TRY(h, hipMemcpyAsync(s0, h->scal_fold, (SC_COUNT + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(s0 + 2 * SC_COUNT, h->d.scal + SC_RZ, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    s0[SC_GINF] = s0[SC_COUNT];
+    for (int i = 0; i < 8; ++i) s0[SC_RZ + i] = s0[2 * SC_COUNT + i];
+    return BA_OK;
+  }
+  HIP_TRY(h, hipMemcpyAsync(s0, h->d.scal, SCAL_BYTES, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
   for (int k = 1; k < SCAL_SLABS; ++k) {
     const double* sk = s0 + (size_t)k * SC_COUNT;
-    for (int i = 0; i < SC_RZ; ++i) {
-      if (i == SC_GINF) s0[i] = std::max(s0[i], sk[i]); else s0[i] += sk[i];
+    for (int i = 0; i < SC_NSUM; ++i) {
+      if (i == SC_GINF || i == SC_GINF_C) s0[i] = std::max(s0[i], sk[i]); else s0[i] += sk[i];
     }
   }
   return BA_OK;
@@ -374,7 +444,7 @@ int lm_solve(ba_handle* h, ba_report* rep) {
   const ba_options& o = h->opt;
   DeviceProblem& d = h->d;
   std::memset(rep, 0, sizeof *rep);
-  rep->nobs = h->n;
+  rep->nobs = (int32_t)h->n_global;
   rep->setup_ms = h->setup_ms;
   const size_t pose_bytes = (size_t)h->C * 7 * sizeof(double), pts_bytes = (size_t)h->L * 3 * sizeof(double);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -388,7 +458,7 @@ int lm_solve(ba_handle* h, ba_report* rep) {
   double* pts_t = h->pts_trial;
 
   double lam = o.lambda0, nu = 2.0;
-  double cost = 0.0, nbehind = 0.0, ginf = 0.0;
+  double cost = 0.0, nbehind = 0.0, ginf = 0.0, ginf_pts = 0.0;
   bool need_lin = true;
   int it = 0, status = BA_STOP_MAX_ITERS;
   while (it < o.max_iters) {
@@ -408,7 +478,7 @@ int lm_solve(ba_handle* h, ba_report* rep) {
     if (need_lin) {
       cost = s[SC_COST];
       nbehind = s[SC_NBEHIND];
-      ginf = s[SC_GINF];
+      ginf_pts = s[SC_GINF];
       if (it == 1) {
         rep->cost0 = cost;
         if (s[SC_ZEROZ] > 0.0)
@@ -417,6 +487,7 @@ int lm_solve(ba_handle* h, ba_report* rep) {
       }
       need_lin = false;
     }
+    ginf = std::max(ginf_pts, s[SC_GINF_C]);
     rep->pcg_iters += pcg_it;
     rep->grad_inf = ginf;
     if (ginf <= o.gtol) {
@@ -424,11 +495,11 @@ int lm_solve(ba_handle* h, ba_report* rep) {
       break;
     }
     const double cost_t = s[SC_COST_T];
-    const double pred = -s[SC_GDOT] - 0.5 * s[SC_DHD];
+    const double pred = -(s[SC_GDOT] + s[SC_GDOT_C]) - 0.5 * (s[SC_DHD] + s[SC_DHD_C]);
     double rho = (pred > 0.0 && std::isfinite(cost_t)) ? (cost - cost_t) / pred : -1.0;
     if (o.guard_cheirality && s[SC_NBEHIND_T] > nbehind) rho = -1.0;
-    const double step_norm = std::sqrt(s[SC_DNORM2]);
-    const double x_norm = std::sqrt(s[SC_XNORM2]);
+    const double step_norm = std::sqrt(s[SC_DNORM2] + s[SC_DNORM2_C]);
+    const double x_norm = std::sqrt(s[SC_XNORM2] + s[SC_XNORM2_C]);
     const bool accept = rho > o.accept_ratio;
     const int hi = rep->n_history < BA_HISTORY ? rep->n_history++ : BA_HISTORY - 1;
     rep->lambda_history[hi] = lam;
@@ -468,7 +539,7 @@ int lm_solve(ba_handle* h, ba_report* rep) {
   rep->lambda = lam;
   rep->iterations = it;
   rep->status = status;
-  rep->rms_reproj = h->n > 0 ? std::sqrt(2.0 * cost / h->n) : 0.0;
+  rep->rms_reproj = h->n_global > 0 ? std::sqrt(2.0 * cost / (double)h->n_global) : 0.0;
   h->has_estimate = true;
   return BA_OK;
 }
@@ -535,6 +606,7 @@ void ba_destroy(ba_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   free_problem(h);
+  if (h->comm && h->rccl) (void)h->rccl->CommDestroy(h->comm);
   if (h->scal_host) (void)hipHostFree(h->scal_host);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -546,6 +618,31 @@ const char* ba_last_error(const ba_handle* h) { return h ? h->err.c_str() : "nul
 int ba_get_kernel_times(ba_handle* h, double* total_ms, int32_t* launches) {
   if (!h || !total_ms || !launches) return BA_ERR_INVALID;
   for (int i = 0; i < BA_KERNEL_CLASSES; ++i) { total_ms[i] = h->ktime_ms[i]; launches[i] = h->kcount[i]; }
+  return BA_OK;
+}
+
+int ba_comm_unique_id(char* id128) {
+  Rccl* r = rccl_load();
+  if (!r || !id128) return BA_ERR_DEVICE;
+  ncclUniqueId id;
+  if (r->GetUniqueId(&id) != ncclSuccess) return BA_ERR_DEVICE;
+  std::memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+  return BA_OK;
+}
+
+int ba_comm_init(ba_handle* h, int32_t rank, int32_t world, const char* id128) {
+  if (!h) return BA_ERR_INVALID;
+  if (world < 1 || rank < 0 || rank >= world || !id128) return fail(h, BA_ERR_INVALID, "bad rank/world/id");
+  if (h->comm) return fail(h, BA_ERR_STATE, "communicator already initialised");
+  h->rccl = rccl_load();
+  if (!h->rccl) return fail(h, BA_ERR_DEVICE, "librccl.so could not be loaded: %s", dlerror());
+  HIP_TRY(h, hipSetDevice(h->device));
+  ncclUniqueId id;
+  std::memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+  NCCL_TRY(h, h->rccl->CommInitRank(&h->comm, world, id, rank));
+  h->rank = rank;
+  h->world = world;
+  free_problem(h);  // a problem set before the communicator existed has a rank-local pattern
   return BA_OK;
 }
 
@@ -663,7 +760,44 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
   }
   std::sort(keys.begin(), keys.end());
   keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  h->n_global = n;
+  if (h->world > 1) {
+    // Every rank must use the SAME block pattern (the all-reduce sums S slot by slot): take the union of
+    // the ranks' patterns.  Also sum the observation counts (for the RMS reprojection error).
+    double cnt[2] = {(double)keys.size(), (double)n};
+    double* d_cnt = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&d_cnt, 4 * sizeof(double)));
+    HIP_TRY(h, hipMemcpy(d_cnt, cnt, 2 * sizeof(double), hipMemcpyHostToDevice));
+    NCCL_TRY(h, h->rccl->GroupStart());
+    NCCL_TRY(h, h->rccl->AllReduce(d_cnt, d_cnt + 2, 1, ncclDouble, ncclMax, h->comm, h->stream));
+    NCCL_TRY(h, h->rccl->AllReduce(d_cnt + 1, d_cnt + 3, 1, ncclDouble, ncclSum, h->comm, h->stream));
+    NCCL_TRY(h, h->rccl->GroupEnd());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(cnt, d_cnt + 2, 2 * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(d_cnt);
+    const size_t kmax = (size_t)cnt[0];
+    h->n_global = (long)cnt[1];
+    std::vector<int64_t> mine(kmax, -1), all((size_t)h->world * kmax);
+    std::copy(keys.begin(), keys.end(), mine.begin());
+    int64_t *d_mine = nullptr, *d_all = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&d_mine, kmax * sizeof(int64_t)));
+    HIP_TRY(h, hipMalloc((void**)&d_all, all.size() * sizeof(int64_t)));
+    HIP_TRY(h, hipMemcpy(d_mine, mine.data(), kmax * sizeof(int64_t), hipMemcpyHostToDevice));
+    NCCL_TRY(h, h->rccl->AllGather(d_mine, d_all, kmax, ncclInt64, h->comm, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(all.data(), d_all, all.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    (void)hipFree(d_mine);
+    (void)hipFree(d_all);
+    keys.clear();
+    for (int64_t k : all)
+      if (k >= 0) keys.push_back(k);
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  }
   const int nu = (int)keys.size();
+  // S upper blocks, rhs and Ugc share one allocation (the all-reduce buffer); the mirrored lower blocks
+  // follow after a gap padded to whole blocks, so that "slot * 36" still addresses them
+  const int gap_blocks = (int)((6L * Cf + 27L * C + 35) / 36);
   std::vector<int> urow_ptr(Cf + 1, 0), ucol(nu), urow(nu), diag_slot(Cf), low_of(nu, -1);
   for (int s = 0; s < nu; ++s) {
     urow[s] = (int)(keys[s] / Cf);
@@ -676,7 +810,7 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
   std::vector<int> brow_cnt(Cf + 1, 0);
   for (int s = 0; s < nu; ++s) {
     brow_cnt[urow[s] + 1]++;
-    if (urow[s] != ucol[s]) { low_of[s] = nu + nl++; brow_cnt[ucol[s] + 1]++; }
+    if (urow[s] != ucol[s]) { low_of[s] = nu + gap_blocks + nl++; brow_cnt[ucol[s] + 1]++; }
   }
   std::vector<int> brow_ptr(Cf + 1, 0);
   for (int f = 0; f < Cf; ++f) brow_ptr[f + 1] = brow_ptr[f] + brow_cnt[f + 1];
@@ -755,11 +889,12 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
       (rc = dev_upload(h, &d.bslot, bslot)) || (rc = dev_upload(h, &d.sm_slot, sm_slot)))
     return rc;
   if ((rc = dev_alloc(h, &d.W, (size_t)18 * n)) || (rc = dev_alloc(h, &d.V, (size_t)6 * L)) ||
-      (rc = dev_alloc(h, &d.gp, (size_t)3 * L)) || (rc = dev_alloc(h, &d.Ugc, (size_t)27 * C)) ||
-      (rc = dev_alloc(h, &d.S, (size_t)36 * (nu + nl))) || (rc = dev_alloc(h, &d.rhs, (size_t)6 * Cf)) ||
+      (rc = dev_alloc(h, &d.gp, (size_t)3 * L)) || (rc = dev_alloc(h, &d.Ugc_part, (size_t)27 * C)) ||
+      (rc = dev_alloc(h, &d.S, (size_t)36 * (nu + gap_blocks + nl))) ||
+      (rc = dev_alloc(h, &h->scal_fold, (size_t)SC_COUNT + 8)) ||
       (rc = dev_alloc(h, &d.Ugc_slab, (size_t)nslab_u * 27 * C)) ||
       (rc = dev_alloc(h, &d.S_slab, (size_t)nslab_s * d.s_slab_stride)) ||
-      (rc = dev_alloc(h, &d.Udiag, (size_t)6 * Cf)) || (rc = dev_alloc(h, &d.Minv, (size_t)36 * Cf)) ||
+      (rc = dev_alloc(h, &d.Minv, (size_t)36 * Cf)) ||
       (rc = dev_alloc(h, &d.dc, (size_t)6 * Cf)) || (rc = dev_alloc(h, &d.r, (size_t)6 * Cf)) ||
       (rc = dev_alloc(h, &d.z, (size_t)6 * Cf)) || (rc = dev_alloc(h, &d.p, (size_t)6 * Cf)) ||
       (rc = dev_alloc(h, &d.q, (size_t)6 * Cf)) || (rc = dev_alloc(h, &d.scal, (size_t)SC_COUNT * SCAL_SLABS)) ||
@@ -767,6 +902,9 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
       (rc = dev_alloc(h, &h->poses_init, (size_t)7 * C)) || (rc = dev_alloc(h, &h->pts_cur, (size_t)3 * L)) ||
       (rc = dev_alloc(h, &h->pts_trial, (size_t)3 * L)) || (rc = dev_alloc(h, &h->pts_init, (size_t)3 * L)))
     return rc;
+  d.rhs = d.S + (size_t)36 * nu;
+  d.Ugc = d.rhs + (size_t)6 * Cf;
+  HIP_TRY(h, hipMemset(d.S, 0, (size_t)36 * (nu + gap_blocks + nl) * sizeof(double)));
   HIP_TRY(h, hipMemset(d.V, 0, (size_t)6 * L * sizeof(double)));
   HIP_TRY(h, hipMemset(d.gp, 0, (size_t)3 * L * sizeof(double)));
   HIP_TRY(h, hipMemset(d.dc, 0, (size_t)6 * Cf * sizeof(double)));
@@ -909,10 +1047,12 @@ int ba_debug_linearization(ba_handle* h, const double* poses, const double* poin
       for (int e = 0; e < 18; ++e) W[18 * (size_t)h->obs_src[k] + e] = t[(size_t)e * n + k];
   }
   if (S) {
-    if ((rc = fetch(t, d.S, (size_t)36 * (d.nu + d.nl)))) return rc;
+    if ((rc = fetch(t, d.S, (size_t)36 * d.nu))) return rc;
     if (h->small_solve) {  // the one-workgroup solve applies the damping on the fly; add it for the export
-      std::vector<double> ud;
-      if ((rc = fetch(ud, d.Udiag, (size_t)6 * Cf))) return rc;
+      std::vector<double> ugc, ud((size_t)6 * Cf);
+      if ((rc = fetch(ugc, d.Ugc, (size_t)27 * C))) return rc;
+      for (int f = 0; f < Cf; ++f)
+        for (int i = 0; i < 6; ++i) ud[6 * (size_t)f + i] = ugc[27 * (size_t)h->free2cam[f] + sym6_index(i, i)];
       for (int f = 0; f < Cf; ++f) {
         int sl = -1;
         for (int s2 = h->urow_ptr[f]; s2 < h->urow_ptr[f + 1]; ++s2)

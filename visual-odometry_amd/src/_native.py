@@ -73,6 +73,8 @@ _SIGNATURES = {
     "ba_debug_linearization": (C.c_int, [_P, _D, _D, C.c_double] + [_D] * 9),
     "ba_schur_block_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "ba_get_kernel_times": (C.c_int, [_P, _D, _I]),
+    "ba_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "ba_comm_init": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_char_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -95,6 +97,15 @@ def load_library():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def comm_unique_id() -> bytes:
+    """128-byte RCCL unique id; rank 0 creates it and ships it to the other ranks."""
+    buf = C.create_string_buffer(128)
+    rc = load_library().ba_comm_unique_id(buf)
+    if rc != 0:
+        raise RuntimeError(f"ba_comm_unique_id failed with status {rc} (librccl.so not loadable?)")
+    return buf.raw
 
 
 def _dptr(a: Optional[np.ndarray]):
@@ -151,6 +162,12 @@ class Solver:
         if rc == 2:
             raise ProcessingError(msg)
         raise RuntimeError(f"libba_amd status {rc}: {msg}")
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        """Join the landmark-sharded multi-GPU solve (call before set_problem)."""
+        if len(unique_id) != 128:
+            raise ValidationError("unique_id must be the 128 bytes of comm_unique_id()")
+        self._check(self._lib.ba_comm_init(self._h, rank, world, unique_id))
 
     # -- problem
     def set_problem(self, n_cams, n_pts, obs_cam, obs_pt, obs_uv, intr, fixed=None):
