@@ -20,8 +20,12 @@ for kv in a.opt:
 s = _native.Solver(verbose=a.verbose, profile_kernels=1, **opts)
 t0 = time.time(); s.set_problem(a.C, a.L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"]); print("set_problem %.2fs, S upper blocks %d" % (time.time() - t0, s.schur_block_count()), flush=True)
 s.upload_guess(sc["poses_guess"], sc["points_guess"])
+prev = s.kernel_times()
 for _ in range(a.reps):
     rep = s.solve_resident()
+    cur = s.kernel_times()
+    print("rep kernels (avg us, launches):", {k: (round((cur[k][0] - prev[k][0]) / max(cur[k][1] - prev[k][1], 1) * 1e3, 1), cur[k][1] - prev[k][1]) for k in cur}, flush=True)
+    prev = cur
     print(json.dumps({k: v for k, v in rep.items() if not k.endswith("history")}), flush=True)
     print("pcg history", rep["pcg_history"])
 print({k: (round(v[0] / max(v[1], 1) * 1e3, 1), v[1]) for k, v in s.kernel_times().items()})

@@ -30,6 +30,25 @@ enum ScalarSlot {
 constexpr int SCAL_SLABS = 64;
 #define SCAL_MINE(d) ((d).scal + (size_t)(blockIdx.x & (SCAL_SLABS - 1)) * SC_COUNT)
 
+constexpr int LM_HISTORY = 128;  // == BA_HISTORY (include/ba_amd.h)
+
+// Levenberg-Marquardt state that lives on the device: k_lm_decide takes the accept / reject decision
+// and updates the damping, so the host enqueues iterations without waiting for each one.
+struct LmCtrl {
+  // options
+  double ftol, xtol, gtol, lambda_min, lambda_max, accept_ratio;
+  int max_iters, guard_cheirality;
+  // state
+  double lam, nu, cost, cost0, nbehind, ginf_pts, ginf;
+  int sel;       // poses_buf[sel] / pts_buf[sel] hold the current estimate, [sel ^ 1] the trial point
+  int need_lin;  // the next iteration starts with a linearisation
+  int done, status, error;  // error: 1 = z == 0 at the initial guess, 2 = non-finite initial cost
+  int it, accepted, linearizations, pcg_total, n_hist;
+  double cost_hist[LM_HISTORY], lam_hist[LM_HISTORY], trial_hist[LM_HISTORY], rho_hist[LM_HISTORY],
+      ginf_hist[LM_HISTORY], step_hist[LM_HISTORY];
+  int pcg_hist[LM_HISTORY], acc_hist[LM_HISTORY];
+};
+
 struct DeviceProblem {
   int C, Cf, L, L_obs, n;  // cameras, free cameras, landmarks, landmarks with >= 1 observation, observations
   Intrinsics K;
@@ -61,6 +80,8 @@ struct DeviceProblem {
   long s_slab_stride;
   double* dc; double* r; double* z; double* p; double* q;   // PCG vectors (dc is the solution x)
   double* scal;
+  LmCtrl* ctrl;
+  double* poses_buf[2]; double* pts_buf[2];
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -82,11 +103,19 @@ template <int G>
 __global__ __launch_bounds__(64, LIN_WAVES) void k_linearize(DeviceProblem d, const double* __restrict__ poses,
                                                   const double* __restrict__ pts, int lm_per_group) {
   __shared__ double stage[64 * LIN_STRIDE];
+  if (poses == nullptr) {  // solver mode: state and the run / skip decision come from the device-side LM control
+    const LmCtrl* c = d.ctrl;
+    if (c->done || !c->need_lin) return;
+    poses = d.poses_buf[c->sel];
+    pts = d.pts_buf[c->sel];
+  }
   const int lane = threadIdx.x;  // one wave per block
   const int gl = lane & (G - 1);
-  const long group = ((long)blockIdx.x * 64 + lane) / G;
-  const long j0 = min((long)d.L_obs, group * lm_per_group);
-  const long j1 = min((long)d.L_obs, j0 + lm_per_group);
+  // the wave owns GPW * lm_per_group consecutive tracks; in iteration jj its GPW groups take GPW
+  // CONSECUTIVE tracks (coalesced index / pixel loads and W stores across the groups)
+  constexpr int GPW = 64 / G;
+  const long j0 = min((long)d.L_obs, (long)blockIdx.x * GPW * lm_per_group) + lane / G;
+  const long j1 = min((long)d.L_obs, ((long)blockIdx.x + 1) * GPW * lm_per_group);
   const long n = d.n;
   double* __restrict__ Uslab = d.Ugc_slab + (long)(blockIdx.x % d.nslab_u) * d.C * 27;
   double acc[27];
@@ -109,26 +138,41 @@ __global__ __launch_bounds__(64, LIN_WAVES) void k_linearize(DeviceProblem d, co
     cur_cam = -1;
   };
 
-  for (int jj = 0; jj < lm_per_group; ++jj) {
-    const long j = j0 + jj;
-    const bool lm_ok = j < j1;
-    int kb = 0, ke = 0;
-    double P[3] = {0, 0, 0};
-    if (lm_ok) {
-      kb = d.lm_ptr[j]; ke = d.lm_ptr[j + 1];
-      P[0] = pts[3 * j]; P[1] = pts[3 * j + 1]; P[2] = pts[3 * j + 2];
+  // software prefetch of the next track's bounds, first observation and point (hides two dependent
+  // round trips per track)
+  int kb_n = 0, ke_n = 0, cam_n = -1, fr_n = -1;
+  double u_n = 0.0, v_n = 0.0, P_n[3] = {0, 0, 0};
+  auto prefetch = [&](long j) {
+    kb_n = 0; ke_n = 0; cam_n = -1; fr_n = -1;
+    if (j < j1) {
+      kb_n = d.lm_ptr[j]; ke_n = d.lm_ptr[j + 1];
+      P_n[0] = pts[3 * j]; P_n[1] = pts[3 * j + 1]; P_n[2] = pts[3 * j + 2];
+      if (kb_n + gl < ke_n) {
+        cam_n = d.o_cam[kb_n + gl]; fr_n = d.o_free[kb_n + gl];
+        u_n = d.o_u[kb_n + gl]; v_n = d.o_v[kb_n + gl];
+      }
     }
+  };
+  prefetch(j0);
+  for (int jj = 0; jj < lm_per_group; ++jj) {
+    const long j = j0 + (long)jj * GPW;
+    const bool lm_ok = j < j1;
+    const int kb = kb_n, ke = ke_n, cam_first = cam_n, fr_first = fr_n;
+    const double u_first = u_n, v_first = v_n;
+    const double P[3] = {P_n[0], P_n[1], P_n[2]};
+    prefetch(j + GPW);
     double v[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
     for (int k0 = kb; __any(k0 < ke); k0 += G) {
       const int k = k0 + gl;
       const bool act = k < ke;
-      const int cam = act ? d.o_cam[k] : -1;
-      const bool is_free = act && d.cam2free[cam] >= 0;
+      const bool first = (k0 == kb);
+      const int cam = !act ? -1 : first ? cam_first : d.o_cam[k];
+      const bool is_free = act && (first ? fr_first : d.o_free[k]) >= 0;
       // flush BEFORE the linearisation so that only the accumulators are live across it
       if (__any(is_free && cur_cam >= 0 && cam != cur_cam)) flush();
       if (act) {
         double r[2], Jc[12], Jp[6], zc;
-        linearize_obs(d.K, poses + 7 * cam, P, d.o_u[k], d.o_v[k], r, Jc, Jp, zc);
+        linearize_obs(d.K, poses + 7 * cam, P, first ? u_first : d.o_u[k], first ? v_first : d.o_v[k], r, Jc, Jp, zc);
         nbehind += (zc <= 0.0);
         nzero += (zc == 0.0);
         cost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
@@ -145,11 +189,17 @@ __global__ __launch_bounds__(64, LIN_WAVES) void k_linearize(DeviceProblem d, co
 #pragma unroll
           for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
         }
+#ifndef DBG_NO_WSTORE
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
           for (int c = 0; c < 3; ++c) d.W[(long)(3 * i + c) * n + k] = Jc[i] * Jp[c] + Jc[6 + i] * Jp[3 + c];
+#endif
+#ifdef DBG_NO_UACC
+        if (false) {
+#else
         if (is_free) {
+#endif
           cur_cam = cam;
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
@@ -192,6 +242,12 @@ __global__ __launch_bounds__(256) void k_cost(DeviceProblem d,
                                               const double* __restrict__ poses, const double* __restrict__ pts,
                                               int cost_slot, int behind_slot, double* __restrict__ res_out) {
   __shared__ double red[4];
+  if (poses == nullptr) {  // solver mode: evaluate the trial point
+    const LmCtrl* c = d.ctrl;
+    if (c->done) return;
+    poses = d.poses_buf[c->sel ^ 1];
+    pts = d.pts_buf[c->sel ^ 1];
+  }
   double cost = 0.0;
   int nbehind = 0, nzero = 0;
   for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < d.n; k += (long)gridDim.x * blockDim.x) {
@@ -241,8 +297,9 @@ __global__ __launch_bounds__(256) void k_export_jac(DeviceProblem d,
 
 // ------------------------------------------------------------------------------------------------
 // k_reduce_U: Ugc[c][e] = sum over slabs; inf-norm of the camera gradient.  One thread per entry.
-__global__ __launch_bounds__(256) void k_reduce_U(DeviceProblem d) {
+__global__ __launch_bounds__(256) void k_reduce_U(DeviceProblem d, int solver_mode) {
   __shared__ double red[4];
+  if (solver_mode && (d.ctrl->done || !d.ctrl->need_lin)) return;
   // 16 entries x 16 slab-lanes per block: lane l sums slabs l, l+16, ...; shuffle-reduce over lanes
   const int e_in_blk = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const long t = (long)blockIdx.x * 16 + e_in_blk;
@@ -267,7 +324,8 @@ __global__ __launch_bounds__(256) void k_reduce_U(DeviceProblem d) {
 
 // k_reduce_S: S (upper blocks) = sum of the slabs (+ partial U on the diagonal blocks), rhs = partial gc
 // + sum of the slabs' rhs part, Ugc = partial U/gc.  One thread per entry of [nu*36 | 6*Cf | 27*C].
-__global__ __launch_bounds__(256) void k_reduce_S(DeviceProblem d) {
+__global__ __launch_bounds__(256) void k_reduce_S(DeviceProblem d, int solver_mode) {
+  if (solver_mode && d.ctrl->done) return;
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long nS = (long)d.nu * 36, nR = 6L * d.Cf, nU = 27L * d.C;
   if (t >= nS + nR + nU) return;
@@ -319,11 +377,15 @@ template <int G>
 __global__ __launch_bounds__(64, 2) void k_schur(DeviceProblem d, double lam, double min_diag, int lm_per_group) {
   __shared__ double stage[64 * SCHUR_STRIDE];
   __shared__ double stage_r[64 * 7];
+  if (lam < 0.0) {  // solver mode
+    if (d.ctrl->done) return;
+    lam = d.ctrl->lam;
+  }
   const int lane = threadIdx.x;  // one wave per block
   const int gl = lane & (G - 1);
-  const long group = ((long)blockIdx.x * 64 + lane) / G;
-  const long j0 = min((long)d.L_obs, group * lm_per_group);
-  const long j1 = min((long)d.L_obs, j0 + lm_per_group);
+  constexpr int GPW = 64 / G;  // same track-to-group interleaving as k_linearize
+  const long j0 = min((long)d.L_obs, (long)blockIdx.x * GPW * lm_per_group) + lane / G;
+  const long j1 = min((long)d.L_obs, ((long)blockIdx.x + 1) * GPW * lm_per_group);
   const long n = d.n;
   double acc[36], accr[6];
 #pragma unroll
@@ -388,10 +450,10 @@ __global__ __launch_bounds__(64, 2) void k_schur(DeviceProblem d, double lam, do
   };
   prefetch(j0);
   for (int jj = 0; jj < lm_per_group; ++jj) {
-    const long j = j0 + jj;
+    const long j = j0 + (long)jj * GPW;
     const bool lm_ok = j < j1;
     const int kb = kb_n, npairs = np_n, fa_first = fa_n, fb_first = fb_n;
-    prefetch(j + 1);
+    prefetch(j + GPW);
     double v[6] = {1, 0, 0, 1, 0, 1}, vi[6], g[3] = {0, 0, 0};
     if (lm_ok) {
 #pragma unroll
@@ -449,6 +511,10 @@ __global__ __launch_bounds__(64, 2) void k_schur(DeviceProblem d, double lam, do
 // invert the diagonal blocks into the block-Jacobi preconditioner, copy upper off-diagonal blocks,
 // transposed, into their lower mirror slots.  One thread per upper slot.
 __global__ __launch_bounds__(256) void k_damp_mirror(DeviceProblem d, double lam, double min_diag) {
+  if (lam < 0.0) {
+    if (d.ctrl->done) return;
+    lam = d.ctrl->lam;
+  }
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= d.nu) return;
   double* Sb = d.S + (long)s * 36;
@@ -477,8 +543,12 @@ __global__ __launch_bounds__(256) void k_damp_mirror(DeviceProblem d, double lam
 // ------------------------------------------------------------------------------------------------
 // Block-Jacobi PCG on S dc = -rhs.  Vectors are [Cf][6]; one thread per scalar row.
 // All step lengths are computed on the device from reduced scalars; the host only polls SC_DONE.
-__global__ __launch_bounds__(256) void k_pcg_init(DeviceProblem d) {
+__global__ __launch_bounds__(256) void k_pcg_init(DeviceProblem d, int solver_mode) {
   __shared__ double red[4];
+  if (solver_mode && d.ctrl->done) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) d.scal[SC_DONE] = 1.0;
+    return;
+  }
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   double rz = 0.0;
   if (t < 6 * d.Cf) {
@@ -585,6 +655,10 @@ __global__ __launch_bounds__(256) void k_pcg_dir(DeviceProblem d, double tol2, i
 // Bound: latency (barriers + LDS), not HBM: S is read once (288 B per block).
 // k_block_precond: Minv_f = (S_ff + lam * max(diag U_f, min_diag))^-1, one thread per free camera.
 __global__ __launch_bounds__(64) void k_block_precond(DeviceProblem d, double lam, double min_diag) {
+  if (lam < 0.0) {
+    if (d.ctrl->done) return;
+    lam = d.ctrl->lam;
+  }
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= d.Cf) return;
   double A[36];
@@ -657,6 +731,10 @@ template <int NB>
 __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, double lam, double min_diag,
                                                                double tol2, int max_iter) {
   extern __shared__ double sm[];
+  if (lam < 0.0) {
+    if (d.ctrl->done) return;
+    lam = d.ctrl->lam;
+  }
   const int N = 6 * d.Cf;
   double* rbuf[2] = {sm, sm + N};
   double* p = sm + 2 * N;
@@ -778,6 +856,12 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
 __global__ __launch_bounds__(256) void k_pose_update(DeviceProblem d, const double* __restrict__ poses,
                                                      double* __restrict__ poses_t) {
   __shared__ double red[4];
+  if (poses == nullptr) {
+    const LmCtrl* c = d.ctrl;
+    if (c->done) return;
+    poses = d.poses_buf[c->sel];
+    poses_t = d.poses_buf[c->sel ^ 1];
+  }
   const int cam = blockIdx.x * blockDim.x + threadIdx.x;
   double gd = 0.0, dhd = 0.0, dn = 0.0, xn = 0.0, gmax = 0.0;
   if (cam < d.C) {
@@ -835,6 +919,13 @@ __global__ __launch_bounds__(256) void k_backsub(DeviceProblem d, double lam, do
                                                  const double* __restrict__ pts, double* __restrict__ pts_t,
                                                  int lm_per_group) {
   __shared__ double red[4];
+  if (lam < 0.0) {
+    const LmCtrl* c = d.ctrl;
+    if (c->done) return;
+    lam = c->lam;
+    pts = d.pts_buf[c->sel];
+    pts_t = d.pts_buf[c->sel ^ 1];
+  }
   const int lane = threadIdx.x & (G - 1);
   const long group = ((long)blockIdx.x * blockDim.x + threadIdx.x) / G;
   const long j0 = group * lm_per_group;
@@ -913,4 +1004,85 @@ __global__ __launch_bounds__(64) void k_fold_scalars(DeviceProblem d, double* __
   if (replicated && !is_root) v = 0.0;
   if (i == SC_GINF) { out[SC_COUNT] = v; v = 0.0; }
   out[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_lm_decide: the Levenberg-Marquardt bookkeeping of one iteration, on the device (one wave).
+// Folds the privatised scalar copies (or takes the rank-combined values from `folded`), then does
+// exactly what the host used to do after a read-back: gain ratio, accept / reject, Nielsen's lambda
+// update, scipy-style termination tests (scipy/optimize/_lsq/common.py:705-717 vocabulary).
+__global__ __launch_bounds__(64) void k_lm_decide(DeviceProblem d, const double* __restrict__ folded) {
+  LmCtrl* c = d.ctrl;
+  if (c->done) return;
+  __shared__ double s[SC_COUNT];
+  const int i = threadIdx.x;
+  if (i < SC_NSUM) {
+    double v = 0.0;
+    if (folded) {
+      v = (i == SC_GINF) ? folded[SC_COUNT] : folded[i];
+    } else {
+      const bool is_max = (i == SC_GINF || i == SC_GINF_C);
+      for (int k = 0; k < SCAL_SLABS; ++k) {
+        const double x = d.scal[(size_t)k * SC_COUNT + i];
+        v = is_max ? fmax(v, x) : v + x;
+      }
+    }
+    s[i] = v;
+  }
+  __syncthreads();
+  if (i != 0) return;
+  const int pcg_it = (int)d.scal[SC_PCGIT];
+  const int it = ++c->it;
+  if (c->need_lin) {
+    c->cost = s[SC_COST];
+    c->nbehind = s[SC_NBEHIND];
+    c->ginf_pts = s[SC_GINF];
+    c->linearizations++;
+    c->need_lin = 0;
+    if (it == 1) {
+      c->cost0 = c->cost;
+      if (s[SC_ZEROZ] > 0.0) { c->error = 1; c->done = 1; return; }
+      if (!isfinite(c->cost)) { c->error = 2; c->done = 1; return; }
+    }
+  }
+  const double cost = c->cost;
+  const double ginf = fmax(c->ginf_pts, s[SC_GINF_C]);
+  c->ginf = ginf;
+  c->pcg_total += pcg_it;
+  if (ginf <= c->gtol) { c->status = 1; c->done = 1; return; }
+  const double cost_t = s[SC_COST_T];
+  const double pred = -(s[SC_GDOT] + s[SC_GDOT_C]) - 0.5 * (s[SC_DHD] + s[SC_DHD_C]);
+  double rho = (pred > 0.0 && isfinite(cost_t)) ? (cost - cost_t) / pred : -1.0;
+  if (c->guard_cheirality && s[SC_NBEHIND_T] > c->nbehind) rho = -1.0;
+  const double step_norm = sqrt(s[SC_DNORM2] + s[SC_DNORM2_C]);
+  const double x_norm = sqrt(s[SC_XNORM2] + s[SC_XNORM2_C]);
+  const bool accept = rho > c->accept_ratio;
+  const int hi = c->n_hist < LM_HISTORY ? c->n_hist++ : LM_HISTORY - 1;
+  c->lam_hist[hi] = c->lam;
+  c->pcg_hist[hi] = pcg_it;
+  c->acc_hist[hi] = accept;
+  c->trial_hist[hi] = cost_t;
+  c->rho_hist[hi] = rho;
+  c->ginf_hist[hi] = ginf;
+  c->step_hist[hi] = step_norm;
+  bool stop = false;
+  if (accept) {
+    const double dF = cost - cost_t;
+    c->sel ^= 1;
+    c->cost = cost_t;
+    c->nbehind = s[SC_NBEHIND_T];
+    c->accepted++;
+    const double t = 2.0 * rho - 1.0;
+    c->lam = fmax(c->lambda_min, c->lam * fmax(1.0 / 3.0, 1.0 - t * t * t));
+    c->nu = 2.0;
+    c->need_lin = 1;
+    if (dF <= c->ftol * cost_t) { c->status = 2; stop = true; }
+    else if (step_norm <= c->xtol * (x_norm + c->xtol)) { c->status = 3; stop = true; }
+  } else {
+    c->lam = fmin(c->lambda_max, c->lam * c->nu);
+    c->nu *= 2.0;
+    if (step_norm <= c->xtol * (x_norm + c->xtol)) { c->status = 3; stop = true; }
+  }
+  c->cost_hist[hi] = c->cost;
+  if (stop || it >= c->max_iters) c->done = 1;  // status stays 0 (max_iters) unless a test fired
 }

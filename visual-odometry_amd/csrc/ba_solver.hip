@@ -16,6 +16,7 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>  // types and prototypes only: librccl.so is dlopen()ed by ba_comm_init
 
 namespace {
@@ -81,8 +82,8 @@ struct ba_handle {
 
   DeviceProblem d{};
   std::vector<void*> allocs;  // everything to hipFree
-  double *poses_cur = nullptr, *poses_trial = nullptr, *poses_init = nullptr;
-  double *pts_cur = nullptr, *pts_trial = nullptr, *pts_init = nullptr;
+  double *poses_cur = nullptr, *poses_init = nullptr;  // poses_cur / pts_cur: where the last estimate lives
+  double *pts_cur = nullptr, *pts_init = nullptr;
   double* scal_host = nullptr;  // pinned
   double* stage = nullptr;      // pinned staging for pose / point transfers
   size_t stage_bytes = 0;
@@ -90,7 +91,9 @@ struct ba_handle {
   // optional HIP-event timing per kernel class (opt.profile_kernels)
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
-  struct Span { int cls; hipEvent_t a, b; };
+  struct Span { int cls; hipEvent_t a, b; int iter; };
+  int span_iter = 0;
+  LmCtrl* ctrl_host = nullptr;  // pinned
   std::vector<Span> spans;
   double ktime_ms[BA_KERNEL_CLASSES] = {0, 0, 0, 0, 0, 0};
   int kcount[BA_KERNEL_CLASSES] = {0, 0, 0, 0, 0, 0};
@@ -140,29 +143,18 @@ hipEvent_t next_event(ba_handle* h) {
   return h->ev_pool[h->ev_used++];
 }
 
-// RAII bracket: records an event pair around the launches issued while it is alive.
-struct KSpan {
-  ba_handle* h;
-  int cls;
-  hipEvent_t a = nullptr;
-  KSpan(ba_handle* h_, int cls_, int launches = 1) : h(h_), cls(cls_) {
-    if (!h->opt.profile_kernels) return;
-    a = next_event(h);
-    (void)hipEventRecord(a, h->stream);
-    h->kcount[cls] += launches;
-  }
-  ~KSpan() {
-    if (!a) return;
-    hipEvent_t b = next_event(h);
-    (void)hipEventRecord(b, h->stream);
-    h->spans.push_back({cls, a, b});
-  }
-};
-
-void collect_spans(ba_handle* h) {  // call after the stream is idle
+// Call after the stream is idle.  Launches enqueued after the solver terminated, and linearise launches
+// of iterations that followed a rejected step, exited at their first instruction: they are not counted.
+void collect_spans(ba_handle* h, const LmCtrl& c) {
   for (auto& s : h->spans) {
+    bool ran = s.iter < c.it;
+    if (ran && s.cls == KT_LIN && s.iter > 0)
+      ran = s.iter - 1 < LM_HISTORY ? c.acc_hist[s.iter - 1] != 0 : false;
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) h->ktime_ms[s.cls] += ms;
+    if (ran && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+      h->ktime_ms[s.cls] += ms;
+      h->kcount[s.cls] += 1;
+    }
   }
   h->spans.clear();
   h->ev_used = 0;
@@ -211,133 +203,126 @@ int env_int(const char* name, int dflt) {
 }
 
 constexpr size_t SCAL_BYTES = (size_t)SCAL_SLABS * SC_COUNT * sizeof(double);
+static_assert(LM_HISTORY == BA_HISTORY, "device and ABI history lengths differ");
 
-// read back every copy of the scalar block and fold them into copy 0 (sum; max for SC_GINF)
+// read back every copy of the scalar block and fold them into copy 0 (sum; max for the inf-norms)
 int fetch_scalars(ba_handle* h);
 
 inline int grid_for(long items, int block = 256) { return (int)std::max<long>(1, (items + block - 1) / block); }
 
 // ---------------------------------------------------------------------------------------------- launches
-void launch_linearize(ba_handle* h, const double* poses, const double* pts) {
-  const DeviceProblem& d = h->d;
-  const long groups = (d.L_obs + h->lpg_lin - 1) / h->lpg_lin;
-  const int G = h->g_lin;
-  const int grid = grid_for(groups * G, 64);
-  switch (G) {
-    case 8: k_linearize<8><<<grid, 64, 0, h->stream>>>(d, poses, pts, h->lpg_lin); break;
-    case 16: k_linearize<16><<<grid, 64, 0, h->stream>>>(d, poses, pts, h->lpg_lin); break;
-    case 32: k_linearize<32><<<grid, 64, 0, h->stream>>>(d, poses, pts, h->lpg_lin); break;
-    default: k_linearize<64><<<grid, 64, 0, h->stream>>>(d, poses, pts, h->lpg_lin); break;
+// The four streaming kernels are launched through hipExtLaunchKernelGGL when kernel timing is on: the
+// start / stop events are attached to the launch itself, so the measured span is the kernel's execution
+// (agrees with rocprofv3's per-dispatch duration) and costs no extra API call.
+template <class... KArgs, class... Args>
+void launch_timed(ba_handle* h, int cls, void (*kern)(KArgs...), int grid, int block, Args... args) {
+  if (h->opt.profile_kernels) {
+    hipEvent_t a = next_event(h), b = next_event(h);
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, h->stream, a, b, 0, args...);
+    h->spans.push_back({cls, a, b, h->span_iter});
+  } else {
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, h->stream, args...);
   }
 }
 
+// poses / pts == nullptr: solver mode (state and run/skip decision come from the device-side LM control)
+void launch_linearize(ba_handle* h, const double* poses, const double* pts) {
+  const DeviceProblem& d = h->d;
+  const int G = h->g_lin, lpg = h->lpg_lin;
+  const int grid = grid_for(d.L_obs, (64 / G) * lpg);
+  switch (G) {
+    case 8: launch_timed(h, KT_LIN, k_linearize<8>, grid, 64, d, poses, pts, lpg); break;
+    case 16: launch_timed(h, KT_LIN, k_linearize<16>, grid, 64, d, poses, pts, lpg); break;
+    case 32: launch_timed(h, KT_LIN, k_linearize<32>, grid, 64, d, poses, pts, lpg); break;
+    default: launch_timed(h, KT_LIN, k_linearize<64>, grid, 64, d, poses, pts, lpg); break;
+  }
+}
+
+// lam < 0: solver mode
 void launch_backsub(ba_handle* h, double lam, const double* pts, double* pts_t) {
   const DeviceProblem& d = h->d;
-  const long groups = (d.L_obs + h->lpg_back - 1) / h->lpg_back;
-  const int G = h->g_lin;
+  const int G = h->g_lin, lpg = h->lpg_back;
+  const long groups = (d.L_obs + lpg - 1) / lpg;
   const int grid = grid_for(groups * G);
   const double md = h->opt.min_diag;
   switch (G) {
-    case 8: k_backsub<8><<<grid, 256, 0, h->stream>>>(d, lam, md, pts, pts_t, h->lpg_back); break;
-    case 16: k_backsub<16><<<grid, 256, 0, h->stream>>>(d, lam, md, pts, pts_t, h->lpg_back); break;
-    case 32: k_backsub<32><<<grid, 256, 0, h->stream>>>(d, lam, md, pts, pts_t, h->lpg_back); break;
-    default: k_backsub<64><<<grid, 256, 0, h->stream>>>(d, lam, md, pts, pts_t, h->lpg_back); break;
+    case 8: launch_timed(h, KT_BACKSUB, k_backsub<8>, grid, 256, d, lam, md, pts, pts_t, lpg); break;
+    case 16: launch_timed(h, KT_BACKSUB, k_backsub<16>, grid, 256, d, lam, md, pts, pts_t, lpg); break;
+    case 32: launch_timed(h, KT_BACKSUB, k_backsub<32>, grid, 256, d, lam, md, pts, pts_t, lpg); break;
+    default: launch_timed(h, KT_BACKSUB, k_backsub<64>, grid, 256, d, lam, md, pts, pts_t, lpg); break;
   }
 }
 
 void launch_schur(ba_handle* h, double lam) {
   const DeviceProblem& d = h->d;
-  const long groups = (d.L_obs + h->lpg_schur - 1) / h->lpg_schur;
-  const int G = h->g_schur;
-  const int grid = grid_for(groups * G, 64);
+  const int G = h->g_schur, lpg = h->lpg_schur;
+  const int grid = grid_for(d.L_obs, (64 / G) * lpg);
   const double md = h->opt.min_diag;
   switch (G) {
-    case 8: k_schur<8><<<grid, 64, 0, h->stream>>>(d, lam, md, h->lpg_schur); break;
-    case 16: k_schur<16><<<grid, 64, 0, h->stream>>>(d, lam, md, h->lpg_schur); break;
-    case 32: k_schur<32><<<grid, 64, 0, h->stream>>>(d, lam, md, h->lpg_schur); break;
-    default: k_schur<64><<<grid, 64, 0, h->stream>>>(d, lam, md, h->lpg_schur); break;
+    case 8: launch_timed(h, KT_SCHUR, k_schur<8>, grid, 64, d, lam, md, lpg); break;
+    case 16: launch_timed(h, KT_SCHUR, k_schur<16>, grid, 64, d, lam, md, lpg); break;
+    case 32: launch_timed(h, KT_SCHUR, k_schur<32>, grid, 64, d, lam, md, lpg); break;
+    default: launch_timed(h, KT_SCHUR, k_schur<64>, grid, 64, d, lam, md, lpg); break;
   }
 }
 
 void launch_cost(ba_handle* h, const double* poses, const double* pts, int cost_slot, int behind_slot,
                  double* res_out) {
   const int grid = std::min(grid_for(h->d.n), 256 * 16);
-  k_cost<<<grid, 256, 0, h->stream>>>(h->d, poses, pts, cost_slot, behind_slot, res_out);
+  launch_timed(h, KT_COST, k_cost, grid, 256, h->d, poses, pts, cost_slot, behind_slot, res_out);
 }
 
-// linearise at (poses, pts): zero accumulators, blocks U V W gc gp, cost into scal[SC_COST]
-int do_linearize(ba_handle* h, const double* poses, const double* pts) {
-  HIP_TRY(h, hipMemsetAsync(h->d.scal, 0, SCAL_BYTES, h->stream));
-  {
-    KSpan t(h, KT_OTHER, 1);
-    HIP_TRY(h, hipMemsetAsync(h->d.Ugc_slab, 0, (size_t)h->d.nslab_u * h->C * 27 * sizeof(double), h->stream));
-  }
-  {
-    KSpan t(h, KT_LIN);
-    launch_linearize(h, poses, pts);
-  }
-  {
-    KSpan t(h, KT_OTHER, 1);
-    k_reduce_U<<<grid_for(27L * h->C, 16), 256, 0, h->stream>>>(h->d);
-  }
+// One allocation holds [Ugc slabs | scalar copies | S slabs]: a linearising iteration clears all of it
+// with ONE memset, a re-solve after a rejected step clears [scalar copies | S slabs].
+int clear_accumulators(ba_handle* h, bool with_u) {
+  const DeviceProblem& d = h->d;
+  const size_t u_bytes = (size_t)d.nslab_u * h->C * 27 * sizeof(double);
+  const size_t rest = SCAL_BYTES + (size_t)d.nslab_s * d.s_slab_stride * sizeof(double);
+  if (with_u) HIP_TRY(h, hipMemsetAsync(d.Ugc_slab, 0, u_bytes + rest, h->stream));
+  else HIP_TRY(h, hipMemsetAsync(d.scal, 0, rest, h->stream));
   return BA_OK;
 }
 
-// build S / rhs for damping lam, precondition, solve for dc by block-Jacobi PCG
+// U V W gc gp at (poses, pts) [explicit mode] or at the current estimate if it moved [solver mode]
+void enqueue_linearize(ba_handle* h, const double* poses, const double* pts) {
+  launch_linearize(h, poses, pts);
+  k_reduce_U<<<grid_for(27L * h->C, 16), 256, 0, h->stream>>>(h->d, poses == nullptr);
+}
+
+// build S / rhs for damping lam (lam < 0: solver mode), precondition, solve for dc by block-Jacobi PCG
 int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
   DeviceProblem& d = h->d;
   const ba_options& o = h->opt;
-  {
-    KSpan t(h, KT_OTHER, 1);
-    HIP_TRY(h, hipMemsetAsync(d.S_slab, 0, (size_t)d.nslab_s * d.s_slab_stride * sizeof(double), h->stream));
-  }
-  {
-    KSpan t(h, KT_SCHUR);
-    launch_schur(h, lam);
-  }
-  {
-    KSpan t(h, KT_OTHER, 1);
-    k_reduce_S<<<grid_for(d.s_slab_stride + 27L * d.C), 256, 0, h->stream>>>(d);
-  }
+  const int mode = lam < 0.0;
+  launch_schur(h, lam);
+  k_reduce_S<<<grid_for(d.s_slab_stride + 27L * d.C), 256, 0, h->stream>>>(d, mode);
   const size_t red_count = (size_t)d.nu * 36 + (size_t)6 * d.Cf + (size_t)27 * d.C;
   if (h->world > 1)  // the one exchange step of the path: partial S, reduced rhs, U / gc summed over the shards
     NCCL_TRY(h, h->rccl->AllReduce(d.S, d.S, red_count, ncclDouble, ncclSum, h->comm, h->stream));
   const double tol2 = o.pcg_tol * o.pcg_tol;
   if (h->small_solve) {
-    {
-      KSpan t(h, KT_PCG, 2);
-      k_block_precond<<<grid_for(d.Cf, 64), 64, 0, h->stream>>>(d, lam, o.min_diag);
-      if (d.nu <= SMALL_THREADS)
-        k_solve_small<1><<<1, SMALL_THREADS, h->small_lds, h->stream>>>(d, lam, o.min_diag, tol2, o.pcg_max_iter);
-      else
-        k_solve_small<2><<<1, SMALL_THREADS, h->small_lds, h->stream>>>(d, lam, o.min_diag, tol2, o.pcg_max_iter);
-    }
-    *pcg_iters = -1;  // read from scal after the trial readback
+    k_block_precond<<<grid_for(d.Cf, 64), 64, 0, h->stream>>>(d, lam, o.min_diag);
+    if (d.nu <= SMALL_THREADS)
+      k_solve_small<1><<<1, SMALL_THREADS, h->small_lds, h->stream>>>(d, lam, o.min_diag, tol2, o.pcg_max_iter);
+    else
+      k_solve_small<2><<<1, SMALL_THREADS, h->small_lds, h->stream>>>(d, lam, o.min_diag, tol2, o.pcg_max_iter);
+    *pcg_iters = -1;  // lives in scal[SC_PCGIT]
     // every rank solved the same system; ship rank 0's step so that all replicas of the poses stay
     // bit-identical (LDS atomics make the summation order, hence the last bits, rank-dependent)
     if (h->world > 1) NCCL_TRY(h, h->rccl->Broadcast(d.dc, d.dc, (size_t)6 * d.Cf, ncclDouble, 0, h->comm, h->stream));
     return BA_OK;
   }
-  {
-    KSpan t(h, KT_OTHER, 1);
-    k_damp_mirror<<<grid_for(d.nu), 256, 0, h->stream>>>(d, lam, o.min_diag);
-  }
+  k_damp_mirror<<<grid_for(d.nu), 256, 0, h->stream>>>(d, lam, o.min_diag);
   const int gv = grid_for(6L * d.Cf);
-  {
-    KSpan t(h, KT_PCG, 1);
-    k_pcg_init<<<gv, 256, 0, h->stream>>>(d);
-  }
+  k_pcg_init<<<gv, 256, 0, h->stream>>>(d, mode);
   const int every = std::max(1, o.pcg_check_every);
   int launched = 0;
   while (launched < o.pcg_max_iter) {
     const int nb = std::min(every, o.pcg_max_iter - launched);
-    {
-      KSpan t(h, KT_PCG, 3 * nb);
-      for (int i = 0; i < nb; ++i) {
-        k_pcg_spmv<<<gv, 256, 0, h->stream>>>(d);
-        k_pcg_update<<<gv, 256, 0, h->stream>>>(d);
-        k_pcg_dir<<<gv, 256, 0, h->stream>>>(d, tol2, o.pcg_max_iter);
-      }
+    for (int i = 0; i < nb; ++i) {
+      k_pcg_spmv<<<gv, 256, 0, h->stream>>>(d);
+      k_pcg_update<<<gv, 256, 0, h->stream>>>(d);
+      k_pcg_dir<<<gv, 256, 0, h->stream>>>(d, tol2, o.pcg_max_iter);
     }
     launched += nb;
     if (h->world > 1)  // all ranks must take the same number of PCG batches: follow rank 0's scalars
@@ -352,41 +337,16 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
   return BA_OK;
 }
 
-// step statistics + trial state + trial cost; leaves everything in scal
-int do_trial(ba_handle* h, double lam, const double* poses, const double* pts, double* poses_t, double* pts_t) {
+// step statistics + trial state + trial cost (all arguments null / negative: solver mode)
+void enqueue_trial(ba_handle* h, double lam, const double* poses, const double* pts, double* poses_t, double* pts_t) {
   DeviceProblem& d = h->d;
-  {
-    KSpan t(h, KT_OTHER, 1);
-    k_pose_update<<<grid_for(d.C), 256, 0, h->stream>>>(d, poses, poses_t);
-  }
-  {
-    KSpan t(h, KT_BACKSUB);
-    launch_backsub(h, lam, pts, pts_t);
-  }
-  {
-    KSpan t(h, KT_COST);
-    launch_cost(h, poses_t, pts_t, SC_COST_T, SC_NBEHIND_T, nullptr);
-  }
-  return fetch_scalars(h);
+  k_pose_update<<<grid_for(d.C), 256, 0, h->stream>>>(d, poses, poses_t);
+  launch_backsub(h, lam, pts, pts_t);
+  launch_cost(h, poses_t, pts_t, SC_COST_T, SC_NBEHIND_T, nullptr);
 }
 
 int fetch_scalars(ba_handle* h) {
   double* s0 = h->scal_host;
-  if (h->world > 1) {
-    // fold on the device, combine the ranks (sum; max for the point-gradient norm), read back
-    k_fold_scalars<<<1, 64, 0, h->stream>>>(h->d, h->scal_fold, h->rank == 0);
-    NCCL_TRY(h, h->rccl->GroupStart());
-    NCCL_TRY(h, h->rccl->AllReduce(h->scal_fold, h->scal_fold, SC_NSUM, ncclDouble, ncclSum, h->comm, h->stream));
-    NCCL_TRY(h, h->rccl->AllReduce(h->scal_fold + SC_COUNT, h->scal_fold + SC_COUNT, 1, ncclDouble, ncclMax, h->comm,
-                                   h->stream));
-    NCCL_TRY(h, h->rccl->GroupEnd());
-    HIP_TRY(h, hipMemcpyAsync(s0, h->scal_fold, (SC_COUNT + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(s0 + 2 * SC_COUNT, h->d.scal + SC_RZ, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    s0[SC_GINF] = s0[SC_COUNT];
-    for (int i = 0; i < 8; ++i) s0[SC_RZ + i] = s0[2 * SC_COUNT + i];
-    return BA_OK;
-  }
   HIP_TRY(h, hipMemcpyAsync(s0, h->d.scal, SCAL_BYTES, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   for (int k = 1; k < SCAL_SLABS; ++k) {
@@ -440,6 +400,9 @@ int fetch_state(ba_handle* h, const double* d_poses, const double* d_pts, double
 }
 
 // ---------------------------------------------------------------------------------------------- LM driver
+// The host only ENQUEUES iterations; the accept / reject decision, the damping update and the
+// termination tests run on the device (k_lm_decide).  Every lm_check_every iterations the small
+// control block is read back; iterations enqueued after termination exit at their first instruction.
 int lm_solve(ba_handle* h, ba_report* rep) {
   const ba_options& o = h->opt;
   DeviceProblem& d = h->d;
@@ -447,99 +410,79 @@ int lm_solve(ba_handle* h, ba_report* rep) {
   rep->nobs = (int32_t)h->n_global;
   rep->setup_ms = h->setup_ms;
   const size_t pose_bytes = (size_t)h->C * 7 * sizeof(double), pts_bytes = (size_t)h->L * 3 * sizeof(double);
+  LmCtrl& c = *h->ctrl_host;
+  std::memset(&c, 0, sizeof c);
+  c.ftol = o.ftol; c.xtol = o.xtol; c.gtol = o.gtol;
+  c.lambda_min = o.lambda_min; c.lambda_max = o.lambda_max; c.accept_ratio = o.accept_ratio;
+  c.max_iters = o.max_iters; c.guard_cheirality = o.guard_cheirality;
+  c.lam = o.lambda0; c.nu = 2.0; c.need_lin = 1;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   const auto t0 = clk::now();
-  HIP_TRY(h, hipMemcpyAsync(h->poses_cur, h->poses_init, pose_bytes, hipMemcpyDeviceToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(h->pts_cur, h->pts_init, pts_bytes, hipMemcpyDeviceToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(h->pts_trial, h->pts_init, pts_bytes, hipMemcpyDeviceToDevice, h->stream));
-  double* poses = h->poses_cur;
-  double* poses_t = h->poses_trial;
-  double* pts = h->pts_cur;
-  double* pts_t = h->pts_trial;
+  HIP_TRY(h, hipMemcpyAsync(d.ctrl, &c, sizeof c, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(d.poses_buf[0], h->poses_init, pose_bytes, hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(d.pts_buf[0], h->pts_init, pts_bytes, hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(d.pts_buf[1], h->pts_init, pts_bytes, hipMemcpyDeviceToDevice, h->stream));
 
-  double lam = o.lambda0, nu = 2.0;
-  double cost = 0.0, nbehind = 0.0, ginf = 0.0, ginf_pts = 0.0;
-  bool need_lin = true;
-  int it = 0, status = BA_STOP_MAX_ITERS;
-  while (it < o.max_iters) {
-    ++it;
-    int rc;
-    if (need_lin) {
-      if ((rc = do_linearize(h, poses, pts))) return rc;
-      rep->linearizations++;
-    } else {
-      HIP_TRY(h, hipMemsetAsync(d.scal, 0, SCAL_BYTES, h->stream));
-    }
-    int pcg_it = 0;
-    if ((rc = do_reduced_solve(h, lam, &pcg_it))) return rc;
-    if ((rc = do_trial(h, lam, poses, pts, poses_t, pts_t))) return rc;
-    const double* s = h->scal_host;
-    if (pcg_it < 0) pcg_it = (int)s[SC_PCGIT];
-    if (need_lin) {
-      cost = s[SC_COST];
-      nbehind = s[SC_NBEHIND];
-      ginf_pts = s[SC_GINF];
-      if (it == 1) {
-        rep->cost0 = cost;
-        if (s[SC_ZEROZ] > 0.0)
-          return fail(h, BA_ERR_NUMERICAL, "cannot project points with zero Z coordinates (division by zero)");
-        if (!std::isfinite(cost)) return fail(h, BA_ERR_NUMERICAL, "non-finite cost at the initial guess");
+  const int check_every = h->small_solve ? std::max(1, o.lm_check_every) : 1;
+  const size_t head_bytes = offsetof(LmCtrl, cost_hist);
+  int enq = 0, rc;
+  bool done = false;
+  while (!done && enq < o.max_iters) {
+    const int nb = std::min(check_every, o.max_iters - enq);
+    for (int i = 0; i < nb; ++i, ++enq) {
+      h->span_iter = enq;
+      // a linearisation may or may not run in this iteration (device decides): always clear its slabs
+      if ((rc = clear_accumulators(h, true))) return rc;
+      enqueue_linearize(h, nullptr, nullptr);
+      int pcg_it = 0;
+      if ((rc = do_reduced_solve(h, -1.0, &pcg_it))) return rc;
+      enqueue_trial(h, -1.0, nullptr, nullptr, nullptr, nullptr);
+      if (h->world > 1) {
+        // fold on the device, combine the ranks (sum; max for the point-gradient norm)
+        k_fold_scalars<<<1, 64, 0, h->stream>>>(d, h->scal_fold, h->rank == 0);
+        NCCL_TRY(h, h->rccl->GroupStart());
+        NCCL_TRY(h, h->rccl->AllReduce(h->scal_fold, h->scal_fold, SC_NSUM, ncclDouble, ncclSum, h->comm, h->stream));
+        NCCL_TRY(h, h->rccl->AllReduce(h->scal_fold + SC_COUNT, h->scal_fold + SC_COUNT, 1, ncclDouble, ncclMax,
+                                       h->comm, h->stream));
+        NCCL_TRY(h, h->rccl->GroupEnd());
+        k_lm_decide<<<1, 64, 0, h->stream>>>(d, h->scal_fold);
+      } else {
+        k_lm_decide<<<1, 64, 0, h->stream>>>(d, nullptr);
       }
-      need_lin = false;
     }
-    ginf = std::max(ginf_pts, s[SC_GINF_C]);
-    rep->pcg_iters += pcg_it;
-    rep->grad_inf = ginf;
-    if (ginf <= o.gtol) {
-      status = BA_STOP_GTOL;
-      break;
-    }
-    const double cost_t = s[SC_COST_T];
-    const double pred = -(s[SC_GDOT] + s[SC_GDOT_C]) - 0.5 * (s[SC_DHD] + s[SC_DHD_C]);
-    double rho = (pred > 0.0 && std::isfinite(cost_t)) ? (cost - cost_t) / pred : -1.0;
-    if (o.guard_cheirality && s[SC_NBEHIND_T] > nbehind) rho = -1.0;
-    const double step_norm = std::sqrt(s[SC_DNORM2] + s[SC_DNORM2_C]);
-    const double x_norm = std::sqrt(s[SC_XNORM2] + s[SC_XNORM2_C]);
-    const bool accept = rho > o.accept_ratio;
-    const int hi = rep->n_history < BA_HISTORY ? rep->n_history++ : BA_HISTORY - 1;
-    rep->lambda_history[hi] = lam;
-    rep->pcg_history[hi] = pcg_it;
-    rep->accepted_history[hi] = accept;
-    if (o.verbose)
-      fprintf(stderr, "[ba] it %3d cost %.12e trial %.12e rho %8.3g lam %.2e |g| %.2e |dx| %.2e pcg %d %s\n", it, cost,
-              cost_t, rho, lam, ginf, step_norm, pcg_it, accept ? "accept" : "reject");
-    bool stop = false;
-    if (accept) {
-      const double dF = cost - cost_t;
-      std::swap(poses, poses_t);
-      std::swap(pts, pts_t);
-      cost = cost_t;
-      nbehind = s[SC_NBEHIND_T];
-      rep->accepted++;
-      lam = std::max(o.lambda_min, lam * std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3)));
-      nu = 2.0;
-      need_lin = true;
-      if (dF <= o.ftol * cost) { status = BA_STOP_FTOL; stop = true; }
-      else if (step_norm <= o.xtol * (x_norm + o.xtol)) { status = BA_STOP_XTOL; stop = true; }
-    } else {
-      lam = std::min(o.lambda_max, lam * nu);
-      nu *= 2.0;
-      if (step_norm <= o.xtol * (x_norm + o.xtol)) { status = BA_STOP_XTOL; stop = true; }
-    }
-    rep->cost_history[hi] = cost;
-    if (stop) break;
+    HIP_TRY(h, hipMemcpyAsync(&c, d.ctrl, head_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    done = c.done != 0;
   }
-  // the estimate lives in (poses, pts); make poses_cur / pts_cur point at it
-  if (poses != h->poses_cur) std::swap(h->poses_cur, h->poses_trial);
-  if (pts != h->pts_cur) std::swap(h->pts_cur, h->pts_trial);
+  HIP_TRY(h, hipMemcpyAsync(&c, d.ctrl, sizeof c, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   rep->solve_ms = ms_since(t0);
-  collect_spans(h);
-  rep->cost = cost;
-  rep->lambda = lam;
-  rep->iterations = it;
-  rep->status = status;
-  rep->rms_reproj = h->n_global > 0 ? std::sqrt(2.0 * cost / (double)h->n_global) : 0.0;
+  collect_spans(h, c);
+  if (c.error == 1) return fail(h, BA_ERR_NUMERICAL, "cannot project points with zero Z coordinates (division by zero)");
+  if (c.error == 2) return fail(h, BA_ERR_NUMERICAL, "non-finite cost at the initial guess");
+  h->poses_cur = d.poses_buf[c.sel];
+  h->pts_cur = d.pts_buf[c.sel];
+  rep->cost0 = c.cost0;
+  rep->cost = c.cost;
+  rep->grad_inf = c.ginf;
+  rep->lambda = c.lam;
+  rep->iterations = c.it;
+  rep->accepted = c.accepted;
+  rep->linearizations = c.linearizations;
+  rep->status = c.status;
+  rep->pcg_iters = c.pcg_total;
+  rep->rms_reproj = h->n_global > 0 ? std::sqrt(2.0 * c.cost / (double)h->n_global) : 0.0;
+  rep->n_history = c.n_hist;
+  for (int i = 0; i < c.n_hist; ++i) {
+    rep->cost_history[i] = c.cost_hist[i];
+    rep->lambda_history[i] = c.lam_hist[i];
+    rep->pcg_history[i] = c.pcg_hist[i];
+    rep->accepted_history[i] = c.acc_hist[i];
+    if (o.verbose)
+      fprintf(stderr, "[ba] it %3d cost %.12e trial %.12e rho %8.3g lam %.2e |g| %.2e |dx| %.2e pcg %d %s\n", i + 1,
+              c.cost_hist[i], c.trial_hist[i], c.rho_hist[i], c.lam_hist[i], c.ginf_hist[i], c.step_hist[i],
+              c.pcg_hist[i], c.acc_hist[i] ? "accept" : "reject");
+  }
   h->has_estimate = true;
   return BA_OK;
 }
@@ -573,6 +516,7 @@ void ba_default_options(ba_options* o) {
   o->pcg_tol = 1e-2;
   o->pcg_max_iter = 1000;
   o->pcg_check_every = 10;
+  o->lm_check_every = 2;
   o->device = -1;
   o->verbose = 0;
   o->profile_kernels = 0;
@@ -594,7 +538,8 @@ int ba_create(const ba_options* opt, ba_handle** out) {
   if (dev >= ndev) { delete h; return BA_ERR_INVALID; }
   h->device = dev;
   if (hipSetDevice(dev) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess ||
-      hipHostMalloc((void**)&h->scal_host, SCAL_BYTES) != hipSuccess) {
+      hipHostMalloc((void**)&h->scal_host, SCAL_BYTES) != hipSuccess ||
+      hipHostMalloc((void**)&h->ctrl_host, sizeof(LmCtrl)) != hipSuccess) {
     delete h;
     return BA_ERR_DEVICE;
   }
@@ -608,6 +553,7 @@ void ba_destroy(ba_handle* h) {
   free_problem(h);
   if (h->comm && h->rccl) (void)h->rccl->CommDestroy(h->comm);
   if (h->scal_host) (void)hipHostFree(h->scal_host);
+  if (h->ctrl_host) (void)hipHostFree(h->ctrl_host);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -843,10 +789,12 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
     const int len90 = std::max(1, tmp[q]);
     h->g_lin = env_int("BA_G_LIN", pow2_at_least(len90, 8, 64));
     h->g_schur = env_int("BA_G_SCHUR", pow2_at_least(len90 * (len90 + 1) / 2, 8, 64));
-    const long target_waves = 256L * 4;  // ~4 waves per CU (run-length accumulation wants long ranges)
-    const long groups_lin = target_waves * (64 / h->g_lin), groups_schur = target_waves * (64 / h->g_schur);
-    h->lpg_lin = env_int("BA_LPG_LIN", (int)std::max<long>(1, (L_obs + groups_lin - 1) / groups_lin));
-    h->lpg_schur = env_int("BA_LPG_SCHUR", (int)std::max<long>(1, (L_obs + groups_schur - 1) / groups_schur));
+    // waves per launch: enough to hide latency, few enough that a lane sees long runs of one camera
+    const long waves_lin = 256L * env_int("BA_WAVES_LIN", 8), waves_schur = 256L * env_int("BA_WAVES_SCHUR", 4);
+    const long gpw_lin = 64 / h->g_lin, gpw_schur = 64 / h->g_schur;
+    h->lpg_lin = env_int("BA_LPG_LIN", (int)std::max<long>(1, (L_obs + waves_lin * gpw_lin - 1) / (waves_lin * gpw_lin)));
+    h->lpg_schur = env_int("BA_LPG_SCHUR",
+                           (int)std::max<long>(1, (L_obs + waves_schur * gpw_schur - 1) / (waves_schur * gpw_schur)));
     h->lpg_back = env_int("BA_LPG_BACK", 1);
   }
   // privatised slabs: as many copies as fit a fixed budget, so that few atomics share an address
@@ -892,16 +840,20 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
       (rc = dev_alloc(h, &d.gp, (size_t)3 * L)) || (rc = dev_alloc(h, &d.Ugc_part, (size_t)27 * C)) ||
       (rc = dev_alloc(h, &d.S, (size_t)36 * (nu + gap_blocks + nl))) ||
       (rc = dev_alloc(h, &h->scal_fold, (size_t)SC_COUNT + 8)) ||
-      (rc = dev_alloc(h, &d.Ugc_slab, (size_t)nslab_u * 27 * C)) ||
-      (rc = dev_alloc(h, &d.S_slab, (size_t)nslab_s * d.s_slab_stride)) ||
+      (rc = dev_alloc(h, &d.Ugc_slab, (size_t)nslab_u * 27 * C + (size_t)SC_COUNT * SCAL_SLABS +
+                                          (size_t)nslab_s * d.s_slab_stride)) ||
+      (rc = dev_alloc(h, &d.ctrl, 1)) ||
       (rc = dev_alloc(h, &d.Minv, (size_t)36 * Cf)) ||
       (rc = dev_alloc(h, &d.dc, (size_t)6 * Cf)) || (rc = dev_alloc(h, &d.r, (size_t)6 * Cf)) ||
       (rc = dev_alloc(h, &d.z, (size_t)6 * Cf)) || (rc = dev_alloc(h, &d.p, (size_t)6 * Cf)) ||
-      (rc = dev_alloc(h, &d.q, (size_t)6 * Cf)) || (rc = dev_alloc(h, &d.scal, (size_t)SC_COUNT * SCAL_SLABS)) ||
-      (rc = dev_alloc(h, &h->poses_cur, (size_t)7 * C)) || (rc = dev_alloc(h, &h->poses_trial, (size_t)7 * C)) ||
-      (rc = dev_alloc(h, &h->poses_init, (size_t)7 * C)) || (rc = dev_alloc(h, &h->pts_cur, (size_t)3 * L)) ||
-      (rc = dev_alloc(h, &h->pts_trial, (size_t)3 * L)) || (rc = dev_alloc(h, &h->pts_init, (size_t)3 * L)))
+      (rc = dev_alloc(h, &d.q, (size_t)6 * Cf)) ||
+      (rc = dev_alloc(h, &d.poses_buf[0], (size_t)7 * C)) || (rc = dev_alloc(h, &d.poses_buf[1], (size_t)7 * C)) ||
+      (rc = dev_alloc(h, &h->poses_init, (size_t)7 * C)) || (rc = dev_alloc(h, &d.pts_buf[0], (size_t)3 * L)) ||
+      (rc = dev_alloc(h, &d.pts_buf[1], (size_t)3 * L)) || (rc = dev_alloc(h, &h->pts_init, (size_t)3 * L)))
     return rc;
+  d.scal = d.Ugc_slab + (size_t)nslab_u * 27 * C;
+  d.S_slab = d.scal + (size_t)SC_COUNT * SCAL_SLABS;
+  HIP_TRY(h, hipMemset(d.ctrl, 0, sizeof(LmCtrl)));
   d.rhs = d.S + (size_t)36 * nu;
   d.Ugc = d.rhs + (size_t)6 * Cf;
   HIP_TRY(h, hipMemset(d.S, 0, (size_t)36 * (nu + gap_blocks + nl) * sizeof(double)));
@@ -957,13 +909,13 @@ int ba_evaluate(ba_handle* h, const double* poses, const double* points, double*
   if (!h->has_problem) return fail(h, BA_ERR_STATE, "evaluate before set_problem");
   if (!poses || !points) return fail(h, BA_ERR_INVALID, "null poses/points");
   HIP_TRY(h, hipSetDevice(h->device));
-  int rc = stage_state(h, poses, points, h->poses_trial, h->pts_trial);
+  int rc = stage_state(h, poses, points, h->d.poses_buf[1], h->d.pts_buf[1]);
   if (rc) return rc;
   h->has_estimate = false;  // the trial buffers were clobbered
   double* d_res = nullptr;
   if (residuals) HIP_TRY(h, hipMalloc((void**)&d_res, (size_t)2 * h->n * sizeof(double)));
   HIP_TRY(h, hipMemsetAsync(h->d.scal, 0, SCAL_BYTES, h->stream));
-  launch_cost(h, h->poses_trial, h->pts_trial, SC_COST_T, SC_NBEHIND_T, d_res);
+  launch_cost(h, h->d.poses_buf[1], h->d.pts_buf[1], SC_COST_T, SC_NBEHIND_T, d_res);
   if (residuals)
     HIP_TRY(h, hipMemcpyAsync(residuals, d_res, (size_t)2 * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if ((rc = fetch_scalars(h))) return rc;
@@ -980,13 +932,13 @@ int ba_jacobian_blocks(ba_handle* h, const double* poses, const double* points, 
   if (!h->has_problem) return fail(h, BA_ERR_STATE, "jacobian_blocks before set_problem");
   if (!poses || !points || !Jc || !Jp) return fail(h, BA_ERR_INVALID, "null argument");
   HIP_TRY(h, hipSetDevice(h->device));
-  int rc = stage_state(h, poses, points, h->poses_trial, h->pts_trial);
+  int rc = stage_state(h, poses, points, h->d.poses_buf[1], h->d.pts_buf[1]);
   if (rc) return rc;
   h->has_estimate = false;
   double *dJc = nullptr, *dJp = nullptr;
   HIP_TRY(h, hipMalloc((void**)&dJc, (size_t)12 * h->n * sizeof(double)));
   HIP_TRY(h, hipMalloc((void**)&dJp, (size_t)6 * h->n * sizeof(double)));
-  k_export_jac<<<std::min(grid_for(h->n), 4096), 256, 0, h->stream>>>(h->d, h->poses_trial, h->pts_trial, dJc, dJp);
+  k_export_jac<<<std::min(grid_for(h->n), 4096), 256, 0, h->stream>>>(h->d, h->d.poses_buf[1], h->d.pts_buf[1], dJc, dJp);
   HIP_TRY(h, hipMemcpyAsync(Jc, dJc, (size_t)12 * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipMemcpyAsync(Jp, dJp, (size_t)6 * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1002,16 +954,22 @@ int ba_debug_linearization(ba_handle* h, const double* poses, const double* poin
   if (!h->has_problem) return fail(h, BA_ERR_STATE, "debug_linearization before set_problem");
   if (!poses || !points) return fail(h, BA_ERR_INVALID, "null poses/points");
   HIP_TRY(h, hipSetDevice(h->device));
-  int rc = stage_state(h, poses, points, h->poses_cur, h->pts_cur);
+  double* P0 = h->d.poses_buf[0];
+  double* X0 = h->d.pts_buf[0];
+  double* P1 = h->d.poses_buf[1];
+  double* X1 = h->d.pts_buf[1];
+  int rc = stage_state(h, poses, points, P0, X0);
   if (rc) return rc;
   h->has_estimate = false;
   const DeviceProblem& d = h->d;
   const int C = h->C, Cf = h->Cf, L = h->L, n = h->n;
-  if ((rc = do_linearize(h, h->poses_cur, h->pts_cur))) return rc;
+  if ((rc = clear_accumulators(h, true))) return rc;
+  enqueue_linearize(h, P0, X0);
   int pcg_it = 0;
   if ((rc = do_reduced_solve(h, lambda, &pcg_it))) return rc;
-  HIP_TRY(h, hipMemcpyAsync(h->pts_trial, h->pts_cur, (size_t)3 * L * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-  if ((rc = do_trial(h, lambda, h->poses_cur, h->pts_cur, h->poses_trial, h->pts_trial))) return rc;
+  HIP_TRY(h, hipMemcpyAsync(X1, X0, (size_t)3 * L * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  enqueue_trial(h, lambda, P0, X0, P1, X1);
+  if ((rc = fetch_scalars(h))) return rc;
   auto fetch = [&](std::vector<double>& dst, const double* src, size_t count) -> int {
     dst.resize(count);
     HIP_TRY(h, hipMemcpy(dst.data(), src, count * sizeof(double), hipMemcpyDeviceToHost));
@@ -1090,7 +1048,7 @@ int ba_debug_linearization(ba_handle* h, const double* poses, const double* poin
   }
   if (dp) {
     std::vector<double> a, b;
-    if ((rc = fetch(a, h->pts_trial, (size_t)3 * L)) || (rc = fetch(b, h->pts_cur, (size_t)3 * L))) return rc;
+    if ((rc = fetch(a, X1, (size_t)3 * L)) || (rc = fetch(b, X0, (size_t)3 * L))) return rc;
     for (int j = 0; j < L; ++j)
       for (int e = 0; e < 3; ++e)
         dp[3 * (size_t)h->lm_internal_to_user[j] + e] = j < h->L_obs ? a[3 * (size_t)j + e] - b[3 * (size_t)j + e] : 0.0;

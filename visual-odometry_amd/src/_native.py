@@ -25,7 +25,7 @@ class BaOptions(C.Structure):
         ("lambda0", C.c_double), ("lambda_min", C.c_double), ("lambda_max", C.c_double),
         ("min_diag", C.c_double), ("accept_ratio", C.c_double), ("guard_cheirality", C.c_int32),
         ("linear_solver", C.c_int32), ("pcg_tol", C.c_double), ("pcg_max_iter", C.c_int32),
-        ("pcg_check_every", C.c_int32), ("device", C.c_int32), ("verbose", C.c_int32),
+        ("pcg_check_every", C.c_int32), ("lm_check_every", C.c_int32), ("device", C.c_int32), ("verbose", C.c_int32),
         ("profile_kernels", C.c_int32),
     ]
 
