@@ -34,7 +34,7 @@ constexpr int LM_HISTORY = 128;  // == BA_HISTORY (include/ba_amd.h)
 
 // Levenberg-Marquardt state that lives on the device: k_lm_decide takes the accept / reject decision
 // and updates the damping, so the host enqueues iterations without waiting for each one.
-struct LmCtrl {
+struct LmHead {
   // options
   double ftol, xtol, gtol, lambda_min, lambda_max, accept_ratio;
   int max_iters, guard_cheirality;
@@ -44,10 +44,13 @@ struct LmCtrl {
   int need_lin;  // the next iteration starts with a linearisation
   int done, status, error;  // error: 1 = z == 0 at the initial guess, 2 = non-finite initial cost
   int it, accepted, linearizations, pcg_total, n_hist;
+};
+struct LmCtrl : LmHead {
   double cost_hist[LM_HISTORY], lam_hist[LM_HISTORY], trial_hist[LM_HISTORY], rho_hist[LM_HISTORY],
       ginf_hist[LM_HISTORY], step_hist[LM_HISTORY];
   int pcg_hist[LM_HISTORY], acc_hist[LM_HISTORY];
 };
+static_assert(sizeof(LmHead) % 8 == 0, "LmHead must not have tail padding");
 
 struct DeviceProblem {
   int C, Cf, L, L_obs, n;  // cameras, free cameras, landmarks, landmarks with >= 1 observation, observations
@@ -67,6 +70,14 @@ struct DeviceProblem {
   const int* bcol;       // [nb]
   const int* bslot;      // [nb]
   const int* sm_slot;    // [nu]  upper slots in diagonal-major order (k_solve_small item order)
+  const int* sch_lm;     // [n_chunks + 1] first landmark of each k_schur_staged chunk
+  const int* sch_k;      // [n_chunks + 1] first observation of each chunk (= lm_ptr[sch_lm[.]])
+  const unsigned* sch_flush;  // [n_chunks] bit s: the wave writes its accumulators out before step s of the chunk
+  const int* sch_blk_row;     // [blocks]   first contribution row of each block of k_schur_staged
+  const int* ctr_ptr;         // [nu + 1]   inverted index: contribution rows of each upper S block ...
+  const int* ctr_row;         // [...]      ... in ascending row order (fixed summation order)
+  double* contrib;            // [rows][CTR_ROW] contribution rows (6x6 block | 6 rhs entries)
+  int n_chunks;          // 0: some track is too long for the staged kernel, k_schur + k_reduce_S are used
   int nu, nl, nb;
   // state
   double* W; double* V; double* gp; double* Ugc;
@@ -504,6 +515,250 @@ __global__ __launch_bounds__(64, 2) void k_schur(DeviceProblem d, double lam, do
   }
   flush();
   if (nbad) atomic_add_f64(&SCAL_MINE(d)[SC_BADV], (double)nbad);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_schur_staged: the reduced-system build for problems whose tracks have at most 10 observations
+// (<= 64 pairs: every pair of a track has a lane of its own).  ba_set_problem cuts the landmark list
+// into chunks of <= SCH_CAP observations / <= SCH_MAXLM landmarks and gives each block `cpb` of them.
+// k_schur reads W straight from HBM inside a dependent chain and adds its blocks into S with fp64
+// atomics (which execute at the memory side, ~1.3 TB/s chip-wide); here a wave
+//   1. loads a whole chunk with coalesced, independent loads (lane t takes observation t: its 18 W
+//      values and camera slot; lane l takes landmark l: V, gp, track start) into REGISTERS while the
+//      pairs of the previous chunk are being multiplied (software pipeline: HBM latency is hidden),
+//   2. inverts the damped V blocks (one per lane), forms Y = W Vd^-1 ONCE per observation and parks
+//      Y | W in LDS (SYW_STRIDE doubles per observation),
+//   3. runs the pair products Y_a W_b^T out of LDS, accumulating in registers along a run of
+//      tracks with the same camera signature,
+//   4. at the end of a run (the host marked those steps in sch_flush: the structure is static)
+//      writes its 64 x 42 accumulators (6x6 block | 6 rhs entries per lane) as ONE contiguous
+//      contribution tile with plain coalesced stores.  k_gather_S then sums, for every S block, the
+//      rows that the host's inverted index lists for it: no atomics, no memset, and S is bitwise
+//      reproducible from run to run.
+// Algorithmic bytes are those of k_schur, but W is read from HBM exactly once.
+constexpr int SCH_CAP = 64;     // observations per chunk (= lanes of a wave)
+constexpr int SCH_MAXLM = 32;   // landmarks per chunk
+constexpr int SCH_MAXLEN = 10;  // longest track the staged kernel takes (55 pairs <= 64 lanes)
+constexpr int SCH_MAXCPB = 32;  // chunks per block
+constexpr int SYW_STRIDE = 38;  // Y[18] | W[18] | 2 pad doubles (rows stay 16-byte aligned)
+constexpr int CTR_ROW = 42;     // doubles per contribution row: 6x6 block | 6 reduced-rhs entries
+constexpr int FLUSH_NV = 14, FLUSH_STRIDE = 15;
+
+template <int G>
+__global__ __launch_bounds__(64, 1) void k_schur_staged(DeviceProblem d, double lam, double min_diag, int cpb) {
+  __shared__ double stage[64 * FLUSH_STRIDE];
+  __shared__ __align__(16) double sYW[SCH_CAP * SYW_STRIDE];
+  __shared__ double sVi[SCH_MAXLM * 9];  // Vd^-1 (6) | gp (3) per landmark of the chunk
+  __shared__ int sFree[SCH_CAP];
+  __shared__ int sKb[SCH_MAXLM + 1];
+  __shared__ int sTab[3][SCH_MAXCPB + 1];  // this block's chunks: first landmark | first observation | flush bits
+  if (lam < 0.0) {  // solver mode
+    if (d.ctrl->done) return;
+    lam = d.ctrl->lam;
+  }
+  const int c0 = blockIdx.x * cpb, c1 = min(d.n_chunks, c0 + cpb);
+  if (c0 >= c1) return;
+  const int lane = threadIdx.x;  // one wave per block
+  if (lane <= c1 - c0) {
+    sTab[0][lane] = d.sch_lm[c0 + lane];
+    sTab[1][lane] = d.sch_k[c0 + lane];
+    sTab[2][lane] = lane < c1 - c0 ? (int)d.sch_flush[c0 + lane] : 0;
+  }
+  const int gl = lane & (G - 1), grp = lane / G;
+  constexpr int GPW = 64 / G;
+  const long n = d.n, L = d.L;
+  double acc[36], accr[6];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) accr[i] = 0.0;
+  bool cur_sym = false;
+  int nbad = 0;
+  double* __restrict__ out = d.contrib + (long)d.sch_blk_row[blockIdx.x] * CTR_ROW;
+  __syncthreads();
+
+  auto flush = [&]() {  // wave-uniform: every lane calls it
+#pragma unroll
+    for (int q = 0; q < CTR_ROW / FLUSH_NV; ++q) {
+#pragma unroll
+      for (int e = 0; e < FLUSH_NV; ++e) {
+        const int t = FLUSH_NV * q + e;
+        double v;
+        if (t < 36) {
+          const int i = t / 6, c = t - 6 * i;
+          // two observations of one landmark in the same image: block + block^T
+          v = cur_sym ? acc[6 * i + c] + acc[6 * c + i] : acc[t];
+        } else {
+          v = accr[t - 36];
+        }
+        stage[lane * FLUSH_STRIDE + e] = -v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < FLUSH_NV; ++k) {  // 64 rows x FLUSH_NV entries, consecutive lanes -> consecutive addresses
+        const int idx = lane + 64 * k, row = idx / FLUSH_NV, e = idx - FLUSH_NV * row;
+        out[row * CTR_ROW + FLUSH_NV * q + e] = stage[row * FLUSH_STRIDE + e];
+      }
+      __syncthreads();
+    }
+    out += 64 * CTR_ROW;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) accr[i] = 0.0;
+    cur_sym = false;
+  };
+
+  // pair owned by this lane: p = gl = b (b + 1) / 2 + a, a <= b (static per lane)
+  int b0 = (int)((sqrt(8.0 * gl + 1.0) - 1.0) * 0.5);
+  while ((b0 + 1) * (b0 + 2) / 2 <= gl) ++b0;
+  while (b0 * (b0 + 1) / 2 > gl) --b0;
+  const int a0 = gl - b0 * (b0 + 1) / 2;
+
+  // registers of the chunk in flight (raw loaded values only: arithmetic on them would make the
+  // compiler wait for the loads right here)
+  double pw[18], pv[6], pg[3];
+  int pfree = -1, plm = 0, pkb = 0, p_j0 = 0, p_k0 = 0, p_nobs = 0, p_nc = 0;
+  auto issue = [&](int ci) {
+    const int j0 = sTab[0][ci - c0], j1 = sTab[0][ci - c0 + 1], k0 = sTab[1][ci - c0], k1 = sTab[1][ci - c0 + 1];
+    p_j0 = j0;
+    p_k0 = k0;
+    p_nobs = k1 - k0;
+    p_nc = j1 - j0;
+    if (lane < p_nobs) {
+#pragma unroll
+      for (int r = 0; r < 18; ++r) pw[r] = d.W[(long)r * n + k0 + lane];
+      pfree = d.o_free[k0 + lane];
+      plm = d.o_lm[k0 + lane];
+    }
+    if (lane < p_nc) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) pv[i] = d.V[(long)i * L + j0 + lane];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) pg[i] = d.gp[(long)i * L + j0 + lane];
+    }
+    if (lane <= p_nc) pkb = d.lm_ptr[j0 + lane];
+  };
+#pragma unroll
+  for (int r = 0; r < 18; ++r) pw[r] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) pv[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) pg[i] = 0.0;
+  issue(c0);
+  for (int ci = c0; ci < c1; ++ci) {
+    const int nobs = p_nobs, nc = p_nc, j0 = p_j0, k0 = p_k0;
+    const unsigned fbits = (unsigned)sTab[2][ci - c0];
+    __syncthreads();  // the pairs of the previous chunk are done with the LDS tiles
+    if (lane < nc) {
+      double vi[6];
+      const double det = damped_inv3(pv, lam, min_diag, vi);
+      if (!(det > 0.0)) ++nbad;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) sVi[lane * 9 + i] = vi[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) sVi[lane * 9 + 6 + i] = pg[i];
+    }
+    if (lane <= nc) sKb[lane] = pkb - k0;
+    if (lane < nobs) sFree[lane] = pfree;
+    __syncthreads();
+    if (lane < nobs) {
+      const int li = plm - j0;
+      double vi[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) vi[i] = sVi[li * 9 + i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        double y[3];
+        sym3_mul(vi, &pw[3 * i], y);
+        sYW[lane * SYW_STRIDE + 3 * i] = y[0];
+        sYW[lane * SYW_STRIDE + 3 * i + 1] = y[1];
+        sYW[lane * SYW_STRIDE + 3 * i + 2] = y[2];
+      }
+#pragma unroll
+      for (int r = 0; r < 18; ++r) sYW[lane * SYW_STRIDE + 18 + r] = pw[r];
+    }
+    __syncthreads();
+    if (ci + 1 < c1) issue(ci + 1);  // in flight while the pairs below are multiplied
+    for (int l0 = 0, step = 0; l0 < nc; l0 += GPW, ++step) {
+      if ((fbits >> step) & 1u) flush();
+      const int li = l0 + grp;
+      int kb = 0, npairs = 0;
+      double g[3] = {0, 0, 0};
+      if (li < nc) {
+        kb = sKb[li];
+        const int len = sKb[li + 1] - kb;
+        npairs = len * (len + 1) / 2;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) g[i] = sVi[li * 9 + 6 + i];
+      }
+      bool act = gl < npairs;
+      const int fa = act ? sFree[kb + a0] : -1, fb = act ? sFree[kb + b0] : -1;
+      act = act && fa >= 0 && fb >= 0;
+      if (act) {
+        cur_sym = (fa == fb) && (a0 != b0);
+        const double* __restrict__ Ya = &sYW[(kb + a0) * SYW_STRIDE];
+        const double* __restrict__ Wb = &sYW[(kb + b0) * SYW_STRIDE + 18];
+        double Y[18];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) Y[i] = Ya[i];
+        if (a0 == b0) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) accr[i] += Y[3 * i] * g[0] + Y[3 * i + 1] * g[1] + Y[3 * i + 2] * g[2];
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const double w0 = Wb[3 * c], w1 = Wb[3 * c + 1], w2 = Wb[3 * c + 2];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) acc[6 * i + c] += Y[3 * i] * w0 + Y[3 * i + 1] * w1 + Y[3 * i + 2] * w2;
+        }
+      }
+    }
+  }
+  flush();
+  if (nbad) atomic_add_f64(&SCAL_MINE(d)[SC_BADV], (double)nbad);
+}
+
+// k_gather_S (staged path): S (upper blocks) = sum of the contribution rows that the inverted index
+// lists for each block (+ partial U on the diagonal blocks), rhs = partial gc + the rows' rhs part,
+// Ugc = partial U/gc.  One wave per S block (lanes 0..41 take the 42 entries of a row), then one
+// thread per Ugc entry.  Reads every contribution row once: 336 B per (pair, run, block of k_schur_staged).
+__global__ __launch_bounds__(256) void k_gather_S(DeviceProblem d, int solver_mode) {
+  if (solver_mode && d.ctrl->done) return;
+  const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long w = gt >> 6;
+  const int lane = threadIdx.x & 63;
+  if (w >= d.nu) {
+    const long t = gt - (long)d.nu * 64;
+    if (t < 27L * d.C) d.Ugc[t] = d.Ugc_part[t];
+    return;
+  }
+  const int s = (int)w;
+  const bool diag = d.low_of[s] < 0;
+  if (lane >= (diag ? CTR_ROW : 36)) return;
+  const int r0 = d.ctr_ptr[s], r1 = d.ctr_ptr[s + 1];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int r = r0;
+  for (; r + 4 <= r1; r += 4) {
+    const long q0 = d.ctr_row[r], q1 = d.ctr_row[r + 1], q2 = d.ctr_row[r + 2], q3 = d.ctr_row[r + 3];
+    s0 += d.contrib[q0 * CTR_ROW + lane];
+    s1 += d.contrib[q1 * CTR_ROW + lane];
+    s2 += d.contrib[q2 * CTR_ROW + lane];
+    s3 += d.contrib[q3 * CTR_ROW + lane];
+  }
+  for (; r < r1; ++r) s0 += d.contrib[(long)d.ctr_row[r] * CTR_ROW + lane];
+  double sum = (s0 + s1) + (s2 + s3);
+  const int f = d.urow[s];
+  if (lane < 36) {
+    if (diag) {
+      const int i = lane / 6, c = lane - 6 * i;
+      sum += d.Ugc_part[(long)d.free2cam[f] * 27 + (i <= c ? sym6_index(i, c) : sym6_index(c, i))];
+    }
+    d.S[(long)s * 36 + lane] = sum;
+  } else {
+    const int i = lane - 36;
+    d.rhs[6L * f + i] = sum + d.Ugc_part[(long)d.free2cam[f] * 27 + 21 + i];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1011,78 +1266,99 @@ __global__ __launch_bounds__(64) void k_fold_scalars(DeviceProblem d, double* __
 // Folds the privatised scalar copies (or takes the rank-combined values from `folded`), then does
 // exactly what the host used to do after a read-back: gain ratio, accept / reject, Nielsen's lambda
 // update, scipy-style termination tests (scipy/optimize/_lsq/common.py:705-717 vocabulary).
-__global__ __launch_bounds__(64) void k_lm_decide(DeviceProblem d, const double* __restrict__ folded) {
+__global__ __launch_bounds__(256) void k_lm_decide(DeviceProblem d, const double* __restrict__ folded) {
   LmCtrl* c = d.ctrl;
   if (c->done) return;
+  __shared__ double part[8][SC_COUNT];
   __shared__ double s[SC_COUNT];
-  const int i = threadIdx.x;
-  if (i < SC_NSUM) {
+  const int t = threadIdx.x, i = t & (SC_COUNT - 1), g = t / SC_COUNT;  // 8 groups x 32 slots
+  {
+    const bool is_max = (i == SC_GINF || i == SC_GINF_C);
     double v = 0.0;
-    if (folded) {
-      v = (i == SC_GINF) ? folded[SC_COUNT] : folded[i];
-    } else {
-      const bool is_max = (i == SC_GINF || i == SC_GINF_C);
-      for (int k = 0; k < SCAL_SLABS; ++k) {
-        const double x = d.scal[(size_t)k * SC_COUNT + i];
+    if (!folded) {
+#pragma unroll
+      for (int k = 0; k < SCAL_SLABS / 8; ++k) {
+        const double x = d.scal[(size_t)(g * (SCAL_SLABS / 8) + k) * SC_COUNT + i];
         v = is_max ? fmax(v, x) : v + x;
       }
     }
-    s[i] = v;
+    part[g][i] = v;
   }
   __syncthreads();
-  if (i != 0) return;
+  if (t < SC_NSUM) {
+    double v;
+    if (folded) {
+      v = (t == SC_GINF) ? folded[SC_COUNT] : folded[t];
+    } else {
+      const bool is_max = (t == SC_GINF || t == SC_GINF_C);
+      v = part[0][t];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) v = is_max ? fmax(v, part[k][t]) : v + part[k][t];
+    }
+    s[t] = v;
+  }
+  __syncthreads();
+  if (t != 0) return;
+  // one snapshot of the control head (wide loads, one round trip), written back once at the end
+  LmHead h = *static_cast<const LmHead*>(c);
   const int pcg_it = (int)d.scal[SC_PCGIT];
-  const int it = ++c->it;
-  if (c->need_lin) {
-    c->cost = s[SC_COST];
-    c->nbehind = s[SC_NBEHIND];
-    c->ginf_pts = s[SC_GINF];
-    c->linearizations++;
-    c->need_lin = 0;
+  const int it = ++h.it;
+  bool early = false;
+  if (h.need_lin) {
+    h.cost = s[SC_COST];
+    h.nbehind = s[SC_NBEHIND];
+    h.ginf_pts = s[SC_GINF];
+    h.linearizations++;
+    h.need_lin = 0;
     if (it == 1) {
-      c->cost0 = c->cost;
-      if (s[SC_ZEROZ] > 0.0) { c->error = 1; c->done = 1; return; }
-      if (!isfinite(c->cost)) { c->error = 2; c->done = 1; return; }
+      h.cost0 = h.cost;
+      if (s[SC_ZEROZ] > 0.0) { h.error = 1; h.done = 1; early = true; }
+      else if (!isfinite(h.cost)) { h.error = 2; h.done = 1; early = true; }
     }
   }
-  const double cost = c->cost;
-  const double ginf = fmax(c->ginf_pts, s[SC_GINF_C]);
-  c->ginf = ginf;
-  c->pcg_total += pcg_it;
-  if (ginf <= c->gtol) { c->status = 1; c->done = 1; return; }
-  const double cost_t = s[SC_COST_T];
-  const double pred = -(s[SC_GDOT] + s[SC_GDOT_C]) - 0.5 * (s[SC_DHD] + s[SC_DHD_C]);
-  double rho = (pred > 0.0 && isfinite(cost_t)) ? (cost - cost_t) / pred : -1.0;
-  if (c->guard_cheirality && s[SC_NBEHIND_T] > c->nbehind) rho = -1.0;
-  const double step_norm = sqrt(s[SC_DNORM2] + s[SC_DNORM2_C]);
-  const double x_norm = sqrt(s[SC_XNORM2] + s[SC_XNORM2_C]);
-  const bool accept = rho > c->accept_ratio;
-  const int hi = c->n_hist < LM_HISTORY ? c->n_hist++ : LM_HISTORY - 1;
-  c->lam_hist[hi] = c->lam;
-  c->pcg_hist[hi] = pcg_it;
-  c->acc_hist[hi] = accept;
-  c->trial_hist[hi] = cost_t;
-  c->rho_hist[hi] = rho;
-  c->ginf_hist[hi] = ginf;
-  c->step_hist[hi] = step_norm;
-  bool stop = false;
-  if (accept) {
-    const double dF = cost - cost_t;
-    c->sel ^= 1;
-    c->cost = cost_t;
-    c->nbehind = s[SC_NBEHIND_T];
-    c->accepted++;
-    const double t = 2.0 * rho - 1.0;
-    c->lam = fmax(c->lambda_min, c->lam * fmax(1.0 / 3.0, 1.0 - t * t * t));
-    c->nu = 2.0;
-    c->need_lin = 1;
-    if (dF <= c->ftol * cost_t) { c->status = 2; stop = true; }
-    else if (step_norm <= c->xtol * (x_norm + c->xtol)) { c->status = 3; stop = true; }
-  } else {
-    c->lam = fmin(c->lambda_max, c->lam * c->nu);
-    c->nu *= 2.0;
-    if (step_norm <= c->xtol * (x_norm + c->xtol)) { c->status = 3; stop = true; }
+  if (!early) {
+    const double ginf = fmax(h.ginf_pts, s[SC_GINF_C]);
+    h.ginf = ginf;
+    h.pcg_total += pcg_it;
+    if (ginf <= h.gtol) { h.status = 1; h.done = 1; early = true; }
   }
-  c->cost_hist[hi] = c->cost;
-  if (stop || it >= c->max_iters) c->done = 1;  // status stays 0 (max_iters) unless a test fired
+  if (!early) {
+    const double cost = h.cost;
+    const double cost_t = s[SC_COST_T];
+    const double pred = -(s[SC_GDOT] + s[SC_GDOT_C]) - 0.5 * (s[SC_DHD] + s[SC_DHD_C]);
+    double rho = (pred > 0.0 && isfinite(cost_t)) ? (cost - cost_t) / pred : -1.0;
+    if (h.guard_cheirality && s[SC_NBEHIND_T] > h.nbehind) rho = -1.0;
+    const double step_norm = sqrt(s[SC_DNORM2] + s[SC_DNORM2_C]);
+    const double x_norm = sqrt(s[SC_XNORM2] + s[SC_XNORM2_C]);
+    const bool accept = rho > h.accept_ratio;
+    const int hi = h.n_hist < LM_HISTORY ? h.n_hist++ : LM_HISTORY - 1;
+    c->lam_hist[hi] = h.lam;
+    c->pcg_hist[hi] = pcg_it;
+    c->acc_hist[hi] = accept;
+    c->trial_hist[hi] = cost_t;
+    c->rho_hist[hi] = rho;
+    c->ginf_hist[hi] = h.ginf;
+    c->step_hist[hi] = step_norm;
+    bool stop = false;
+    if (accept) {
+      const double dF = cost - cost_t;
+      h.sel ^= 1;
+      h.cost = cost_t;
+      h.nbehind = s[SC_NBEHIND_T];
+      h.accepted++;
+      const double tt = 2.0 * rho - 1.0;
+      h.lam = fmax(h.lambda_min, h.lam * fmax(1.0 / 3.0, 1.0 - tt * tt * tt));
+      h.nu = 2.0;
+      h.need_lin = 1;
+      if (dF <= h.ftol * cost_t) { h.status = 2; stop = true; }
+      else if (step_norm <= h.xtol * (x_norm + h.xtol)) { h.status = 3; stop = true; }
+    } else {
+      h.lam = fmin(h.lambda_max, h.lam * h.nu);
+      h.nu *= 2.0;
+      if (step_norm <= h.xtol * (x_norm + h.xtol)) { h.status = 3; stop = true; }
+    }
+    c->cost_hist[hi] = h.cost;
+    if (stop || it >= h.max_iters) h.done = 1;  // status stays 0 (max_iters) unless a test fired
+  }
+  *static_cast<LmHead*>(c) = h;
 }

@@ -77,6 +77,7 @@ struct ba_handle {
   std::vector<int> urow_ptr, ucol;
   std::vector<uint8_t> fixed;
   int g_lin = 16, g_schur = 64, lpg_lin = 1, lpg_schur = 1, lpg_back = 1;
+  int schur_cpb = 0;  // > 0: k_schur_staged with this many chunks per block
   bool small_solve = false, small_cached = false;
   size_t small_lds = 0;
 
@@ -256,8 +257,18 @@ void launch_backsub(ba_handle* h, double lam, const double* pts, double* pts_t) 
 void launch_schur(ba_handle* h, double lam) {
   const DeviceProblem& d = h->d;
   const int G = h->g_schur, lpg = h->lpg_schur;
-  const int grid = grid_for(d.L_obs, (64 / G) * lpg);
   const double md = h->opt.min_diag;
+  if (h->schur_cpb > 0) {
+    const int cpb = h->schur_cpb, grid = grid_for(d.n_chunks, cpb);
+    switch (G) {
+      case 8: launch_timed(h, KT_SCHUR, k_schur_staged<8>, grid, 64, d, lam, md, cpb); break;
+      case 16: launch_timed(h, KT_SCHUR, k_schur_staged<16>, grid, 64, d, lam, md, cpb); break;
+      case 32: launch_timed(h, KT_SCHUR, k_schur_staged<32>, grid, 64, d, lam, md, cpb); break;
+      default: launch_timed(h, KT_SCHUR, k_schur_staged<64>, grid, 64, d, lam, md, cpb); break;
+    }
+    return;
+  }
+  const int grid = grid_for(d.L_obs, (64 / G) * lpg);
   switch (G) {
     case 8: launch_timed(h, KT_SCHUR, k_schur<8>, grid, 64, d, lam, md, lpg); break;
     case 16: launch_timed(h, KT_SCHUR, k_schur<16>, grid, 64, d, lam, md, lpg); break;
@@ -295,7 +306,8 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
   const ba_options& o = h->opt;
   const int mode = lam < 0.0;
   launch_schur(h, lam);
-  k_reduce_S<<<grid_for(d.s_slab_stride + 27L * d.C), 256, 0, h->stream>>>(d, mode);
+  if (h->schur_cpb > 0) k_gather_S<<<grid_for(64L * d.nu + 27L * d.C), 256, 0, h->stream>>>(d, mode);
+  else k_reduce_S<<<grid_for(d.s_slab_stride + 27L * d.C), 256, 0, h->stream>>>(d, mode);
   const size_t red_count = (size_t)d.nu * 36 + (size_t)6 * d.Cf + (size_t)27 * d.C;
   if (h->world > 1)  // the one exchange step of the path: partial S, reduced rhs, U / gc summed over the shards
     NCCL_TRY(h, h->rccl->AllReduce(d.S, d.S, red_count, ncclDouble, ncclSum, h->comm, h->stream));
@@ -424,7 +436,7 @@ int lm_solve(ba_handle* h, ba_report* rep) {
   HIP_TRY(h, hipMemcpyAsync(d.pts_buf[1], h->pts_init, pts_bytes, hipMemcpyDeviceToDevice, h->stream));
 
   const int check_every = h->small_solve ? std::max(1, o.lm_check_every) : 1;
-  const size_t head_bytes = offsetof(LmCtrl, cost_hist);
+  const size_t head_bytes = sizeof(LmHead);
   int enq = 0, rc;
   bool done = false;
   while (!done && enq < o.max_iters) {
@@ -445,9 +457,9 @@ int lm_solve(ba_handle* h, ba_report* rep) {
         NCCL_TRY(h, h->rccl->AllReduce(h->scal_fold + SC_COUNT, h->scal_fold + SC_COUNT, 1, ncclDouble, ncclMax,
                                        h->comm, h->stream));
         NCCL_TRY(h, h->rccl->GroupEnd());
-        k_lm_decide<<<1, 64, 0, h->stream>>>(d, h->scal_fold);
+        k_lm_decide<<<1, 256, 0, h->stream>>>(d, h->scal_fold);
       } else {
-        k_lm_decide<<<1, 64, 0, h->stream>>>(d, nullptr);
+        k_lm_decide<<<1, 256, 0, h->stream>>>(d, nullptr);
       }
     }
     HIP_TRY(h, hipMemcpyAsync(&c, d.ctrl, head_bytes, hipMemcpyDeviceToHost, h->stream));
@@ -797,12 +809,104 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
                            (int)std::max<long>(1, (L_obs + waves_schur * gpw_schur - 1) / (waves_schur * gpw_schur)));
     h->lpg_back = env_int("BA_LPG_BACK", 1);
   }
+  // ---- k_schur_staged tables: chunks (consecutive landmarks, <= SCH_CAP observations, <= SCH_MAXLM
+  // landmarks), the steps at which a wave must write its accumulators out (some lane's camera pair
+  // changes), the contribution rows those write-outs fill, and the inverted index S block -> rows.
+  std::vector<int> sch_lm(1, 0), sch_k(1, 0), sch_blk_row(1, 0), ctr_ptr(nu + 1, 0), ctr_row;
+  std::vector<unsigned> sch_flush;
+  long contrib_rows = 0;
+  h->schur_cpb = 0;
+  {
+    int maxlen = 0;
+    for (int j = 0; j < L_obs; ++j) maxlen = std::max(maxlen, lm_ptr[j + 1] - lm_ptr[j]);
+    if (env_int("BA_SCHUR_STAGED", 1) != 0 && maxlen <= SCH_MAXLEN && L_obs > 0) {
+      const int G = pow2_at_least(maxlen * (maxlen + 1) / 2, 8, 64), GPW = 64 / G;
+      sch_lm.clear(); sch_k.clear(); sch_blk_row.clear();
+      for (int j = 0; j < L_obs;) {
+        sch_lm.push_back(j);
+        sch_k.push_back(lm_ptr[j]);
+        int j1 = j + 1;
+        while (j1 < L_obs && j1 - j < SCH_MAXLM && lm_ptr[j1 + 1] - lm_ptr[j] <= SCH_CAP) ++j1;
+        j = j1;
+      }
+      sch_lm.push_back(L_obs);
+      sch_k.push_back(lm_ptr[L_obs]);
+      const int n_chunks = (int)sch_lm.size() - 1;
+      const int want_blocks = 256 * env_int("BA_SCHUR_BLOCKS_PER_CU", 5);
+      const int cpb = std::min(SCH_MAXCPB, env_int("BA_CPB", std::max(1, (n_chunks + want_blocks - 1) / want_blocks)));
+      const int n_blocks = (n_chunks + cpb - 1) / cpb;
+      sch_flush.assign(n_chunks, 0u);
+      // pair (a, b) of lane gl: gl = b (b + 1) / 2 + a
+      int pa[64], pb[64];
+      for (int b2 = 0, p = 0; p < 64; ++b2)
+        for (int a2 = 0; a2 <= b2 && p < 64; ++a2, ++p) { pa[p] = a2; pb[p] = b2; }
+      struct Cur { int fa, fb; bool sym; };
+      std::vector<std::pair<int, int>> contributors;  // (upper slot, contribution row)
+      auto slot_of = [&](int fa, int fb) {
+        const int* lo = ucol.data() + urow_ptr[fa];
+        const int* hi = ucol.data() + urow_ptr[fa + 1];
+        return (int)(std::lower_bound(lo, hi, fb) - ucol.data());
+      };
+      for (int blk = 0; blk < n_blocks; ++blk) {
+        Cur cur[64];
+        for (auto& c : cur) c = Cur{-1, -1, false};
+        sch_blk_row.push_back((int)contrib_rows);
+        auto write_out = [&]() {
+          for (int lane = 0; lane < 64; ++lane)
+            if (cur[lane].fa >= 0) {
+              contributors.emplace_back(slot_of(cur[lane].fa, cur[lane].fb), (int)(contrib_rows + lane));
+              cur[lane] = Cur{-1, -1, false};
+            }
+          contrib_rows += 64;
+        };
+        for (int ci = blk * cpb; ci < std::min(n_chunks, (blk + 1) * cpb); ++ci) {
+          const int jc = sch_lm[ci], nc = sch_lm[ci + 1] - jc;
+          for (int l0 = 0, step = 0; l0 < nc; l0 += GPW, ++step) {
+            Cur nxt[64];
+            bool need = false;
+            for (int lane = 0; lane < 64; ++lane) {
+              nxt[lane] = Cur{-1, -1, false};
+              const int grp = lane / G, gl = lane % G, li = l0 + grp;
+              if (li >= nc) continue;
+              const int kb = lm_ptr[jc + li], len = lm_ptr[jc + li + 1] - kb;
+              if (gl >= len * (len + 1) / 2) continue;
+              const int fa = o_free[kb + pa[gl]], fb = o_free[kb + pb[gl]];
+              if (fa < 0 || fb < 0) continue;
+              nxt[lane] = Cur{fa, fb, fa == fb && pa[gl] != pb[gl]};
+              if (cur[lane].fa >= 0 && (cur[lane].fa != fa || cur[lane].fb != fb || cur[lane].sym != nxt[lane].sym))
+                need = true;
+            }
+            if (need) { sch_flush[ci] |= 1u << step; write_out(); }
+            for (int lane = 0; lane < 64; ++lane)
+              if (nxt[lane].fa >= 0) cur[lane] = nxt[lane];
+          }
+        }
+        write_out();  // the kernel always ends with one
+        if (contrib_rows > ((long)1 << 31) - 128) break;
+      }
+      const long max_rows = ((long)env_int("BA_CONTRIB_MAX_MB", 16384) << 20) / (CTR_ROW * (long)sizeof(double));
+      if (contrib_rows <= std::min<long>(max_rows, ((long)1 << 31) - 128)) {
+        h->schur_cpb = cpb;
+        h->g_schur = G;
+        h->d.n_chunks = n_chunks;
+        for (auto& c : contributors) ctr_ptr[c.first + 1]++;
+        for (int s2 = 0; s2 < nu; ++s2) ctr_ptr[s2 + 1] += ctr_ptr[s2];
+        ctr_row.resize(contributors.size());
+        std::vector<int> fill(ctr_ptr.begin(), ctr_ptr.end() - 1);
+        for (auto& c : contributors) ctr_row[fill[c.first]++] = c.second;  // rows were generated in ascending order
+      } else {
+        contrib_rows = 0;  // too many distinct camera pairs per landmark range: atomics path
+        sch_lm.assign(1, 0); sch_k.assign(1, 0); sch_blk_row.assign(1, 0); sch_flush.clear();
+      }
+    }
+  }
   // privatised slabs: as many copies as fit a fixed budget, so that few atomics share an address
   {
     const size_t u_bytes = (size_t)C * 27 * sizeof(double);
     const size_t s_bytes = ((size_t)nu * 36 + (size_t)6 * Cf) * sizeof(double);
     h->d.nslab_u = env_int("BA_NSLAB_U", (int)std::min<size_t>(256, std::max<size_t>(1, ((size_t)8 << 20) / u_bytes)));
     h->d.nslab_s = env_int("BA_NSLAB_S", (int)std::min<size_t>(16, std::max<size_t>(1, ((size_t)32 << 20) / s_bytes)));
+    if (h->schur_cpb > 0) h->d.nslab_s = 0;  // the staged path writes contribution rows instead
     h->d.s_slab_stride = (long)nu * 36 + 6L * Cf;
   }
   // one-workgroup reduced solve for small camera systems (vectors + preconditioner in LDS)
@@ -834,7 +938,11 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
       (rc = dev_upload(h, &d.ucol, ucol)) || (rc = dev_upload(h, &d.urow, urow)) ||
       (rc = dev_upload(h, &d.diag_slot, diag_slot)) || (rc = dev_upload(h, &d.low_of, low_of)) ||
       (rc = dev_upload(h, &d.brow_ptr, brow_ptr)) || (rc = dev_upload(h, &d.bcol, bcol)) ||
-      (rc = dev_upload(h, &d.bslot, bslot)) || (rc = dev_upload(h, &d.sm_slot, sm_slot)))
+      (rc = dev_upload(h, &d.bslot, bslot)) || (rc = dev_upload(h, &d.sm_slot, sm_slot)) ||
+      (rc = dev_upload(h, &d.sch_lm, sch_lm)) || (rc = dev_upload(h, &d.sch_k, sch_k)) ||
+      (rc = dev_upload(h, &d.sch_flush, sch_flush)) || (rc = dev_upload(h, &d.sch_blk_row, sch_blk_row)) ||
+      (rc = dev_upload(h, &d.ctr_ptr, ctr_ptr)) || (rc = dev_upload(h, &d.ctr_row, ctr_row)) ||
+      (rc = dev_alloc(h, &d.contrib, (size_t)contrib_rows * CTR_ROW)))
     return rc;
   if ((rc = dev_alloc(h, &d.W, (size_t)18 * n)) || (rc = dev_alloc(h, &d.V, (size_t)6 * L)) ||
       (rc = dev_alloc(h, &d.gp, (size_t)3 * L)) || (rc = dev_alloc(h, &d.Ugc_part, (size_t)27 * C)) ||
