@@ -61,6 +61,7 @@ struct DeviceProblem {
   const int* lm_ptr;     // [L_obs + 1]
   const int* cam2free;   // [C]   -1 = fixed
   const int* free2cam;   // [Cf]
+  const int* fixed_cams; // [C - Cf]
   const int* urow_ptr;   // [Cf + 1] upper-triangle block rows
   const int* ucol;       // [nu]
   const int* urow;       // [nu]   row of each upper slot
@@ -721,43 +722,77 @@ __global__ __launch_bounds__(64, 1) void k_schur_staged(DeviceProblem d, double 
 
 // k_gather_S (staged path): S (upper blocks) = sum of the contribution rows that the inverted index
 // lists for each block (+ partial U on the diagonal blocks), rhs = partial gc + the rows' rhs part,
-// Ugc = partial U/gc.  One wave per S block (lanes 0..41 take the 42 entries of a row), then one
-// thread per Ugc entry.  Reads every contribution row once: 336 B per (pair, run, block of k_schur_staged).
+// Ugc = partial U/gc (the diagonal blocks also sum their camera's k_linearize slabs: no k_reduce_U
+// launch on this path).  One 256-thread block per S block: wave w takes rows w, w + 4, ... of the
+// list (lanes 0..41 = the 42 entries of a row, 8 rows in flight per wave), the four partial sums are
+// combined in a fixed order.  Reads every contribution row once: 336 B per (pair, run, block of
+// k_schur_staged).
 __global__ __launch_bounds__(256) void k_gather_S(DeviceProblem d, int solver_mode) {
-  if (solver_mode && d.ctrl->done) return;
-  const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long w = gt >> 6;
-  const int lane = threadIdx.x & 63;
-  if (w >= d.nu) {
-    const long t = gt - (long)d.nu * 64;
-    if (t < 27L * d.C) d.Ugc[t] = d.Ugc_part[t];
-    return;
+  __shared__ double part[4][64];
+  __shared__ double upart[8][32];
+  __shared__ double ugc[32];
+  int from_slabs = 1;  // U / gc were accumulated by a k_linearize since the last gather
+  if (solver_mode) {
+    if (d.ctrl->done) return;
+    from_slabs = d.ctrl->need_lin;
   }
-  const int s = (int)w;
-  const bool diag = d.low_of[s] < 0;
-  if (lane >= (diag ? CTR_ROW : 36)) return;
-  const int r0 = d.ctr_ptr[s], r1 = d.ctr_ptr[s + 1];
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int r = r0;
-  for (; r + 4 <= r1; r += 4) {
-    const long q0 = d.ctr_row[r], q1 = d.ctr_row[r + 1], q2 = d.ctr_row[r + 2], q3 = d.ctr_row[r + 3];
-    s0 += d.contrib[q0 * CTR_ROW + lane];
-    s1 += d.contrib[q1 * CTR_ROW + lane];
-    s2 += d.contrib[q2 * CTR_ROW + lane];
-    s3 += d.contrib[q3 * CTR_ROW + lane];
-  }
-  for (; r < r1; ++r) s0 += d.contrib[(long)d.ctr_row[r] * CTR_ROW + lane];
-  double sum = (s0 + s1) + (s2 + s3);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const bool extra = (int)blockIdx.x >= d.nu;  // blocks past nu: U / gc of the fixed cameras (exported, never solved for)
+  const int s = extra ? 0 : blockIdx.x;
+  const bool diag = extra || d.low_of[s] < 0;
   const int f = d.urow[s];
+  const long cam27 = (long)(extra ? d.fixed_cams[blockIdx.x - d.nu] : d.free2cam[f]) * 27;
+  if (diag) {
+    // this camera's U (21) | gc (6): sum of the k_linearize slabs (k_reduce_U's job, fused here), or
+    // the values kept from the last linearisation when this is a re-solve with another damping
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    double u = 0.0;
+    if (e < 27) {
+      if (from_slabs) {
+        const long tot = (long)d.C * 27;
+        for (int k = g; k < d.nslab_u; k += 8) u += d.Ugc_slab[(long)k * tot + cam27 + e];
+      } else if (g == 0) {
+        u = d.Ugc_part[cam27 + e];
+      }
+    }
+    upart[g][e] = u;
+  }
+  const int r0 = d.ctr_ptr[s], r1 = extra ? r0 : d.ctr_ptr[s + 1];
+  double acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = 0.0;
+  if (lane < CTR_ROW) {
+    int r = r0 + w;
+    for (; r + 28 < r1; r += 32) {
+      long q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = d.ctr_row[r + 4 * u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += d.contrib[q[u] * CTR_ROW + lane];
+    }
+    for (; r < r1; r += 4) acc[0] += d.contrib[(long)d.ctr_row[r] * CTR_ROW + lane];
+  }
+  part[w][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (diag && threadIdx.x < 27) {
+    double u = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) u += upart[g][threadIdx.x];
+    ugc[threadIdx.x] = u;
+    d.Ugc_part[cam27 + threadIdx.x] = u;
+    d.Ugc[cam27 + threadIdx.x] = u;  // in the buffer the multi-GPU all-reduce sums
+  }
+  __syncthreads();
+  if (extra || w != 0 || lane >= (diag ? CTR_ROW : 36)) return;
+  double sum = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
   if (lane < 36) {
     if (diag) {
       const int i = lane / 6, c = lane - 6 * i;
-      sum += d.Ugc_part[(long)d.free2cam[f] * 27 + (i <= c ? sym6_index(i, c) : sym6_index(c, i))];
+      sum += ugc[i <= c ? sym6_index(i, c) : sym6_index(c, i)];
     }
     d.S[(long)s * 36 + lane] = sum;
   } else {
-    const int i = lane - 36;
-    d.rhs[6L * f + i] = sum + d.Ugc_part[(long)d.free2cam[f] * 27 + 21 + i];
+    d.rhs[6L * f + lane - 36] = sum + ugc[21 + lane - 36];
   }
 }
 

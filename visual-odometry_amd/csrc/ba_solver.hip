@@ -297,6 +297,7 @@ int clear_accumulators(ba_handle* h, bool with_u) {
 // U V W gc gp at (poses, pts) [explicit mode] or at the current estimate if it moved [solver mode]
 void enqueue_linearize(ba_handle* h, const double* poses, const double* pts) {
   launch_linearize(h, poses, pts);
+  if (h->schur_cpb > 0) return;  // staged path: k_gather_S sums the U / gc slabs
   k_reduce_U<<<grid_for(27L * h->C, 16), 256, 0, h->stream>>>(h->d, poses == nullptr);
 }
 
@@ -306,7 +307,7 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
   const ba_options& o = h->opt;
   const int mode = lam < 0.0;
   launch_schur(h, lam);
-  if (h->schur_cpb > 0) k_gather_S<<<grid_for(64L * d.nu + 27L * d.C), 256, 0, h->stream>>>(d, mode);
+  if (h->schur_cpb > 0) k_gather_S<<<d.nu + (d.C - d.Cf), 256, 0, h->stream>>>(d, mode);
   else k_reduce_S<<<grid_for(d.s_slab_stride + 27L * d.C), 256, 0, h->stream>>>(d, mode);
   const size_t red_count = (size_t)d.nu * 36 + (size_t)6 * d.Cf + (size_t)27 * d.C;
   if (h->world > 1)  // the one exchange step of the path: partial S, reduced rhs, U / gc summed over the shards
@@ -832,7 +833,7 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
       sch_lm.push_back(L_obs);
       sch_k.push_back(lm_ptr[L_obs]);
       const int n_chunks = (int)sch_lm.size() - 1;
-      const int want_blocks = 256 * env_int("BA_SCHUR_BLOCKS_PER_CU", 5);
+      const int want_blocks = 256 * env_int("BA_SCHUR_BLOCKS_PER_CU", 4);
       const int cpb = std::min(SCH_MAXCPB, env_int("BA_CPB", std::max(1, (n_chunks + want_blocks - 1) / want_blocks)));
       const int n_blocks = (n_chunks + cpb - 1) / cpb;
       sch_flush.assign(n_chunks, 0u);
@@ -923,6 +924,9 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
   }
 
   // ---- upload structure, allocate state
+  std::vector<int> fixed_cams;
+  for (int c = 0; c < C; ++c)
+    if (h->cam2free[c] < 0) fixed_cams.push_back(c);
   DeviceProblem& d = h->d;
   const int nslab_u = d.nslab_u, nslab_s = d.nslab_s;
   d.C = C; d.Cf = Cf; d.L = L; d.L_obs = L_obs; d.n = n;
@@ -934,7 +938,7 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
       (rc = dev_upload(h, &d.o_src, o_src)) || (rc = dev_upload(h, &d.o_lm, o_lm)) ||
       (rc = dev_upload(h, &d.o_free, o_free)) ||
       (rc = dev_upload(h, &d.lm_ptr, lm_ptr)) || (rc = dev_upload(h, &d.cam2free, h->cam2free)) ||
-      (rc = dev_upload(h, &d.free2cam, h->free2cam)) || (rc = dev_upload(h, &d.urow_ptr, urow_ptr)) ||
+      (rc = dev_upload(h, &d.free2cam, h->free2cam)) || (rc = dev_upload(h, &d.fixed_cams, fixed_cams)) || (rc = dev_upload(h, &d.urow_ptr, urow_ptr)) ||
       (rc = dev_upload(h, &d.ucol, ucol)) || (rc = dev_upload(h, &d.urow, urow)) ||
       (rc = dev_upload(h, &d.diag_slot, diag_slot)) || (rc = dev_upload(h, &d.low_of, low_of)) ||
       (rc = dev_upload(h, &d.brow_ptr, brow_ptr)) || (rc = dev_upload(h, &d.bcol, bcol)) ||
