@@ -191,6 +191,29 @@ __device__ __forceinline__ void atomic_max_nonneg(double* p, double v) {
   atomicMax(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(__double_as_longlong(v)));
 }
 
+// Sum over the 64 lanes of a wave, returned to every lane (wave-uniform: it comes back through
+// v_readlane).  Four DPP steps build the 16-lane row sums (xor 1, xor 2, half-row mirror, row mirror: a
+// few cycles each, no LDS crossbar round trips as ds_bpermute-based shuffles need), then the four row
+// sums are read out of lanes 0 / 16 / 32 / 48.  Fixed summation order.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_move_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_move_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_move_f64<0x141>(v);  // row_half_mirror
+  v += dpp_move_f64<0x140>(v);  // row_mirror
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
 template <int WIDTH>
 __device__ __forceinline__ double group_sum(double v) {
 #pragma unroll

@@ -71,6 +71,7 @@ struct DeviceProblem {
   const int* bcol;       // [nb]
   const int* bslot;      // [nb]
   const int* sm_slot;    // [nu]  upper slots in diagonal-major order (k_solve_small item order)
+  const int* sm_gidx;    // [nb]  k_solve_small gather list, in brow_ptr order: LDS slot offset of each block of a row
   const int* sch_lm;     // [n_chunks + 1] first landmark of each k_schur_staged chunk
   const int* sch_k;      // [n_chunks + 1] first observation of each chunk (= lm_ptr[sch_lm[.]])
   const unsigned* sch_flush;  // [n_chunks] bit s: the wave writes its accumulators out before step s of the chunk
@@ -937,12 +938,17 @@ __global__ __launch_bounds__(256) void k_pcg_dir(DeviceProblem d, double tol2, i
 
 // ------------------------------------------------------------------------------------------------
 // k_solve_small: the whole reduced solve for a small camera system in ONE workgroup and ONE launch:
-// LM damping of the diagonal, block-Jacobi preconditioner, and the complete PCG loop with the
-// vectors in LDS.  With CACHED the upper blocks of S live in registers for the whole solve (each
-// thread owns up to ITEMS rows-of-a-block = 6 doubles each), so a PCG iteration touches no global
-// memory at all; otherwise S is streamed from L2 every iteration.  SpMV uses the symmetry:
-// q_i += B p_j and q_j += B^T p_i for every stored upper block B = S_ij (LDS fp64 atomics).
-// Bound: latency (barriers + LDS), not HBM: S is read once (288 B per block).
+// LM damping of the diagonal and the complete block-Jacobi PCG loop, S in registers (each thread
+// owns up to NB upper 6x6 blocks), vectors and preconditioner in LDS: an iteration touches no global
+// memory.  Built for latency, the only bound here (S is read once, 288 B per block):
+//   * Chronopoulos-Gear form of PCG: ONE fused reduction (r.z and z.Sz) and 3 barriers per iteration
+//     instead of two reductions and 4 barriers (same iterates in exact arithmetic);
+//   * SpMV by symmetry without atomics: thread (i, j) stores B z_j and B^T z_i into its own LDS
+//     slot, row threads then gather the <= (blocks per row) slots listed by sm_gidx in a fixed order
+//     (ds_add_f64 costs ~20 cycles per wave-instruction and made the sum order-dependent);
+//   * wave sums by DPP, not ds_bpermute shuffles;
+//   * the 6 entries of a camera sit in one wave (60 rows per wave), so z = Minv r exchanges r through
+//     LDS without a block barrier.
 // k_block_precond: Minv_f = (S_ff + lam * max(diag U_f, min_diag))^-1, one thread per free camera.
 __global__ __launch_bounds__(64) void k_block_precond(DeviceProblem d, double lam, double min_diag) {
   if (lam < 0.0) {
@@ -963,44 +969,12 @@ __global__ __launch_bounds__(64) void k_block_precond(DeviceProblem d, double la
 }
 
 constexpr int SMALL_THREADS = 512;
-constexpr int SMALL_VPT = 2;  // vector entries per thread: 6 * Cf <= SMALL_VPT * SMALL_THREADS
-
-// Sum over the 512-thread block with ONE barrier: wave shuffle -> red[w] -> barrier -> every thread
-// adds the 8 partials itself.  `red` must not be the array used by the previous call.
-__device__ __forceinline__ double block_sum_small(double v, double* red /*[8]*/) {
-  v = group_sum<64>(v);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  double s = 0.0;
-#pragma unroll
-  for (int w = 0; w < SMALL_THREADS / 64; ++w) s += red[w];
-  return s;
-}
-
-// One stored upper block B = S_ij applied in both directions of the symmetric product:
-// q_i += B p_j and (i != j) q_j += B^T p_i.  Blocks are handed to threads along block diagonals
-// (sm_slot), so the 64 lanes of a wave-instruction hit 64 different i (and j): no LDS conflicts.
-__device__ __forceinline__ void small_apply_block(const double B[36], int i, int j, const double* p, double* q) {
-  double pj[6], pi[6];
-#pragma unroll
-  for (int c = 0; c < 6; ++c) { pj[c] = p[6 * j + c]; pi[c] = p[6 * i + c]; }
-#pragma unroll
-  for (int r = 0; r < 6; ++r) {
-    double a = 0.0;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) a += B[6 * r + c] * pj[c];
-    atomic_add_f64(&q[6 * i + r], a);
-  }
-  if (i != j) {
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      double a = 0.0;
-#pragma unroll
-      for (int r = 0; r < 6; ++r) a += B[6 * r + c] * pi[r];
-      atomic_add_f64(&q[6 * j + c], a);
-    }
-  }
-}
+constexpr int SMALL_VPT = 2;             // vector entries per thread
+constexpr int SMALL_ROWS_PER_WAVE = 60;  // 10 cameras per wave
+constexpr int SMALL_MAX_ROWS = SMALL_VPT * (SMALL_THREADS / 64) * SMALL_ROWS_PER_WAVE;  // 960 = 160 free cameras
+constexpr int SMALL_MAX_NB = 2;          // upper blocks per thread: nu <= 1024
+constexpr int SMALL_GREG = 20;           // gather offsets a row thread keeps in registers
+constexpr int SMALL_CSTRIDE = 13;        // doubles per SpMV slot: B z_j (6) | B^T z_i (6) | pad (bank spread)
 
 __device__ __forceinline__ void small_load_block(const DeviceProblem& d, int t, double lam, double min_diag,
                                                  double B[36], int& i, int& j) {
@@ -1015,8 +989,29 @@ __device__ __forceinline__ void small_load_block(const DeviceProblem& d, int t, 
   }
 }
 
-// NB = upper blocks of S each thread keeps in registers (further blocks are streamed from L2 every
-// iteration).  4 barriers per PCG iteration; x, z stay in registers, r is double-buffered in LDS.
+// One stored upper block B = S_ij, both directions of the symmetric product into the block's own slot
+__device__ __forceinline__ void small_block_products(const double B[36], int i, int j, const double* z, double* out) {
+  double zj[6], zi[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) { zj[c] = z[6 * j + c]; zi[c] = z[6 * i + c]; }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    double a = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) a += B[6 * r + c] * zj[c];
+    out[r] = a;
+  }
+  if (i != j) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double a = 0.0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) a += B[6 * r + c] * zi[r];
+      out[6 + c] = a;
+    }
+  }
+}
+
 template <int NB>
 __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, double lam, double min_diag,
                                                                double tol2, int max_iter) {
@@ -1026,16 +1021,17 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
     lam = d.ctrl->lam;
   }
   const int N = 6 * d.Cf;
-  double* rbuf[2] = {sm, sm + N};
-  double* p = sm + 2 * N;
-  double* q = p + N;
-  double* Minv = q + N;             // [Cf][36]
-  double* redA = Minv + 36 * d.Cf;  // [8]
-  double* redB = redA + 8;          // [8]
-  const int tid = threadIdx.x;
+  double* zv = sm;                  // [N]  z = Minv r: the vector the SpMV multiplies
+  double* rv = zv + N;              // [N]  r, for the wave-local exchange
+  double* Minv = rv + N;            // [Cf][36]
+  double* red = Minv + 36 * d.Cf;   // [8][2]
+  double* slot = red + 16;          // [nu][SMALL_CSTRIDE]
+  int* gl = reinterpret_cast<int*>(slot + (size_t)(d.nu + 1) * SMALL_CSTRIDE);  // [nb] gather list
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
   for (int t = tid; t < 36 * d.Cf; t += SMALL_THREADS) Minv[t] = d.Minv[t];
-  for (int t = tid; t < N; t += SMALL_THREADS) rbuf[0][t] = -d.rhs[t];
+  for (int t = tid; t < d.nb; t += SMALL_THREADS) gl[t] = d.sm_gidx[t];
+  if (tid < SMALL_CSTRIDE) slot[(size_t)d.nu * SMALL_CSTRIDE + tid] = 0.0;
   double B[NB][36];
   int ij[NB];
 #pragma unroll
@@ -1048,94 +1044,116 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
       ij[k] = (i << 16) | j;
     }
   }
-  __syncthreads();
-  double x[SMALL_VPT], z[SMALL_VPT];
-  double part = 0.0;
+  // rows of this thread: wave wv (+ 8 per extra entry), lanes 0..59
+  int ent[SMALL_VPT], g0[SMALL_VPT], g1[SMALL_VPT];
+  double x[SMALL_VPT], r[SMALL_VPT], p[SMALL_VPT], sv[SMALL_VPT], z[SMALL_VPT];
 #pragma unroll
   for (int v = 0; v < SMALL_VPT; ++v) {
-    const int t = tid + v * SMALL_THREADS;
-    x[v] = 0.0;
-    z[v] = 0.0;
-    if (t < N) {
-      const int f = t / 6, i = t - 6 * f;
-      double zi = 0.0;
-#pragma unroll
-      for (int c = 0; c < 6; ++c) zi += Minv[36 * f + 6 * i + c] * rbuf[0][6 * f + c];
-      z[v] = zi;
-      p[t] = zi;
-      q[t] = 0.0;
-      part += rbuf[0][t] * zi;
+    const int t = (wv + (SMALL_THREADS / 64) * v) * SMALL_ROWS_PER_WAVE + lane;
+    ent[v] = (lane < SMALL_ROWS_PER_WAVE && t < N) ? t : -1;
+    x[v] = 0.0; p[v] = 0.0; sv[v] = 0.0; z[v] = 0.0; r[v] = 0.0;
+    g0[v] = 0; g1[v] = 0;
+    if (ent[v] >= 0) {
+      r[v] = -d.rhs[t];
+      rv[t] = r[v];
+      g0[v] = d.brow_ptr[t / 6];
+      g1[v] = d.brow_ptr[t / 6 + 1];
     }
   }
-  double rz = block_sum_small(part, redB);  // barrier inside: p, q visible afterwards
-  const double rz0 = rz;
-  int it = 0, cur = 0;
-  while (it < max_iter && rz > tol2 * rz0 && rz > 0.0) {
-    // (A) q = S p
+  __syncthreads();
+  int gi[SMALL_VPT][SMALL_GREG];  // slot offsets of the row's first blocks (a zeroed slot pads short rows)
 #pragma unroll
-    for (int k = 0; k < NB; ++k)
-      if (ij[k] >= 0) small_apply_block(B[k], ij[k] >> 16, ij[k] & 0xffff, p, q);
-    for (int t = tid + NB * SMALL_THREADS; t < d.nu; t += SMALL_THREADS) {
-      double Bs[36];
-      int i, j;
-      small_load_block(d, t, lam, min_diag, Bs, i, j);
-      small_apply_block(Bs, i, j, p, q);
-    }
-    __syncthreads();
-    // (B) p.q
-    part = 0.0;
+  for (int v = 0; v < SMALL_VPT; ++v)
 #pragma unroll
-    for (int v = 0; v < SMALL_VPT; ++v) {
-      const int t = tid + v * SMALL_THREADS;
-      if (t < N) part += p[t] * q[t];
-    }
-    const double pq = block_sum_small(part, redA);
-    if (!(pq > 0.0)) break;
-    const double alpha = rz / pq;
-    // (C) x += alpha p; r' = r - alpha q (other buffer); z = Minv r'; r'.z
-    const double* ro = rbuf[cur];
-    double* rn = rbuf[cur ^ 1];
-    part = 0.0;
+    for (int k = 0; k < SMALL_GREG; ++k)
+      gi[v][k] = (ent[v] >= 0 && g0[v] + k < g1[v]) ? gl[g0[v] + k] + ent[v] % 6 : d.nu * SMALL_CSTRIDE;
+  auto precondition = [&]() {  // z = Minv r for this thread's rows (r of the camera is in rv), published in zv
 #pragma unroll
-    for (int v = 0; v < SMALL_VPT; ++v) {
-      const int t = tid + v * SMALL_THREADS;
-      if (t < N) {
-        const int f = t / 6, i = t - 6 * f;
+    for (int v = 0; v < SMALL_VPT; ++v)
+      if (ent[v] >= 0) {
+        const int f = ent[v] / 6, i = ent[v] - 6 * f;
         double zi = 0.0;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) zi += Minv[36 * f + 6 * i + c] * (ro[6 * f + c] - alpha * q[6 * f + c]);
-        const double rt = ro[t] - alpha * q[t];
-        rn[t] = rt;
-        x[v] += alpha * p[t];
+        for (int c = 0; c < 6; ++c) zi += Minv[36 * f + 6 * i + c] * rv[6 * f + c];
         z[v] = zi;
-        part += rt * zi;
+        zv[ent[v]] = zi;
       }
-    }
-    const double rzn = block_sum_small(part, redB);
-    const double beta = rzn / rz;
-    // (D) p = z + beta p; clear q
+  };
+  precondition();
+  __syncthreads();
+  double gamma = 0.0, gamma0 = 0.0, gamma_old = 1.0, alpha_old = 1.0;
+  int it = 0;
+  while (true) {
+    // (A) every stored block: B z_j and B^T z_i into its slot
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+      if (ij[k] >= 0)
+        small_block_products(B[k], ij[k] >> 16, ij[k] & 0xffff, zv, slot + (size_t)(tid + k * SMALL_THREADS) * SMALL_CSTRIDE);
+    __syncthreads();
+    // (B) w = S z gathered per row; gamma = r.z, delta = z.w in one reduction
+    double w[SMALL_VPT], pg = 0.0, pd = 0.0;
 #pragma unroll
     for (int v = 0; v < SMALL_VPT; ++v) {
-      const int t = tid + v * SMALL_THREADS;
-      if (t < N) {
-        p[t] = z[v] + beta * p[t];
-        q[t] = 0.0;
+      w[v] = 0.0;
+      if (ent[v] >= 0) {
+        // the first SMALL_GREG slots of the row come from register-held offsets: independent LDS reads
+        double w0 = 0.0, w1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < SMALL_GREG; k += 2) {
+          w0 += slot[gi[v][k]];
+          w1 += slot[gi[v][k + 1]];
+        }
+        const int i = ent[v] % 6;
+        for (int e = g0[v] + SMALL_GREG; e < g1[v]; ++e) w0 += slot[gl[e] + i];
+        w[v] = w0 + w1;
+        pg += r[v] * z[v];
+        pd += w[v] * z[v];
       }
     }
-    rz = rzn;
-    cur ^= 1;
+    pg = wave_sum_dpp(pg);
+    pd = wave_sum_dpp(pd);
+    if (lane == 0) { red[2 * wv] = pg; red[2 * wv + 1] = pd; }
+    __syncthreads();
+    gamma = 0.0;
+    double delta = 0.0;
+#pragma unroll
+    for (int k = 0; k < SMALL_THREADS / 64; ++k) { gamma += red[2 * k]; delta += red[2 * k + 1]; }
+    if (it == 0) gamma0 = gamma;
+#ifdef DBG_SMALL_FIXED
+    if (it >= 32) break;
+#else
+    if (it >= max_iter || !(gamma > tol2 * gamma0) || !(gamma > 0.0)) break;
+#endif
+    const double beta = it ? gamma / gamma_old : 0.0;
+    const double denom = it ? delta - beta * gamma / alpha_old : delta;
+#ifndef DBG_SMALL_FIXED
+    if (!(denom > 0.0)) break;
+#endif
+    const double alpha = gamma / denom;
+    // (C) p = z + beta p; s = w + beta s (= S p); x += alpha p; r -= alpha s; z = Minv r
+#pragma unroll
+    for (int v = 0; v < SMALL_VPT; ++v)
+      if (ent[v] >= 0) {
+        p[v] = z[v] + beta * p[v];
+        sv[v] = w[v] + beta * sv[v];
+        x[v] += alpha * p[v];
+        r[v] -= alpha * sv[v];
+        rv[ent[v]] = r[v];
+      }
+    __builtin_amdgcn_wave_barrier();  // the 6 rows of a camera belong to this wave: LDS keeps a wave's accesses in order
+    precondition();
+    gamma_old = gamma;
+    alpha_old = alpha;
     ++it;
     __syncthreads();
   }
 #pragma unroll
-  for (int v = 0; v < SMALL_VPT; ++v) {
-    const int t = tid + v * SMALL_THREADS;
-    if (t < N) d.dc[t] = x[v];
-  }
+  for (int v = 0; v < SMALL_VPT; ++v)
+    if (ent[v] >= 0) d.dc[ent[v]] = x[v];
   if (tid == 0) {
     d.scal[SC_PCGIT] = (double)it;
-    d.scal[SC_RZ] = rz;
-    d.scal[SC_RZ0] = rz0;
+    d.scal[SC_RZ] = gamma;
+    d.scal[SC_RZ0] = gamma0;
     d.scal[SC_DONE] = 1.0;
   }
 }

@@ -910,11 +910,22 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
     if (h->schur_cpb > 0) h->d.nslab_s = 0;  // the staged path writes contribution rows instead
     h->d.s_slab_stride = (long)nu * 36 + 6L * Cf;
   }
-  // one-workgroup reduced solve for small camera systems (vectors + preconditioner in LDS)
+  // one-workgroup reduced solve for small camera systems (S in registers, vectors + preconditioner +
+  // SpMV slots in LDS)
+  std::vector<int> sm_gidx(nb);
   {
-    h->small_lds = ((size_t)4 * 6 * Cf + (size_t)36 * Cf + 16) * sizeof(double);
-    h->small_solve = env_int("BA_SMALL_SOLVE", 1) && 6 * Cf <= SMALL_VPT * SMALL_THREADS &&
-                     nu <= 4 * SMALL_THREADS && h->small_lds <= 160 * 1024;
+    std::vector<int> inv_sm(nu), up_of_low(nl, -1);
+    for (int t = 0; t < nu; ++t) inv_sm[sm_slot[t]] = t;
+    for (int s2 = 0; s2 < nu; ++s2)
+      if (low_of[s2] >= 0) up_of_low[low_of[s2] - nu - gap_blocks] = s2;
+    for (int e = 0; e < nb; ++e) {
+      const int sl = bslot[e];
+      sm_gidx[e] = sl < nu ? inv_sm[sl] * SMALL_CSTRIDE : inv_sm[up_of_low[sl - nu - gap_blocks]] * SMALL_CSTRIDE + 6;
+    }
+    h->small_lds = ((size_t)2 * 6 * Cf + (size_t)36 * Cf + 16 + (size_t)(nu + 1) * SMALL_CSTRIDE) * sizeof(double) +
+                   (size_t)nb * sizeof(int);
+    h->small_solve = env_int("BA_SMALL_SOLVE", 1) && 6 * Cf <= SMALL_MAX_ROWS &&
+                     nu <= SMALL_MAX_NB * SMALL_THREADS && h->small_lds <= 160 * 1024;
     if (h->small_solve && h->small_lds > 64 * 1024) {
       HIP_TRY(h, hipFuncSetAttribute((const void*)k_solve_small<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)h->small_lds));
@@ -943,6 +954,7 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
       (rc = dev_upload(h, &d.diag_slot, diag_slot)) || (rc = dev_upload(h, &d.low_of, low_of)) ||
       (rc = dev_upload(h, &d.brow_ptr, brow_ptr)) || (rc = dev_upload(h, &d.bcol, bcol)) ||
       (rc = dev_upload(h, &d.bslot, bslot)) || (rc = dev_upload(h, &d.sm_slot, sm_slot)) ||
+      (rc = dev_upload(h, &d.sm_gidx, sm_gidx)) ||
       (rc = dev_upload(h, &d.sch_lm, sch_lm)) || (rc = dev_upload(h, &d.sch_k, sch_k)) ||
       (rc = dev_upload(h, &d.sch_flush, sch_flush)) || (rc = dev_upload(h, &d.sch_blk_row, sch_blk_row)) ||
       (rc = dev_upload(h, &d.ctr_ptr, ctr_ptr)) || (rc = dev_upload(h, &d.ctr_row, ctr_row)) ||
