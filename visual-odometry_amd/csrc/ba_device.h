@@ -195,6 +195,15 @@ __device__ __forceinline__ void atomic_max_nonneg(double* p, double v) {
 // v_readlane).  Four DPP steps build the 16-lane row sums (xor 1, xor 2, half-row mirror, row mirror: a
 // few cycles each, no LDS crossbar round trips as ds_bpermute-based shuffles need), then the four row
 // sums are read out of lanes 0 / 16 / 32 / 48.  Fixed summation order.
+// 1 / x for a positive, finite, normal x: hardware estimate + two Newton steps (full fp64 precision,
+// about a third of the dependent instructions of the IEEE division sequence)
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return r;
+}
+
 template <int CTRL>
 __device__ __forceinline__ double dpp_move_f64(double v) {
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);

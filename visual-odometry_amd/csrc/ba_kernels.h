@@ -1081,15 +1081,28 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
   };
   precondition();
   __syncthreads();
-  double gamma = 0.0, gamma0 = 0.0, gamma_old = 1.0, alpha_old = 1.0;
+  double gamma = 0.0, gamma0 = 0.0, delta_ = 0.0, inv_gamma_old = 1.0, denom_old = 1.0;
+  static_assert(SMALL_THREADS == 512, "the partial sums below are written out for 8 waves");
   int it = 0;
+#ifdef DBG_SMALL_TIMING
+  long long dbgT[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   while (true) {
+#ifdef DBG_SMALL_TIMING
+    const long long t0 = clock64();
+#endif
     // (A) every stored block: B z_j and B^T z_i into its slot
 #pragma unroll
     for (int k = 0; k < NB; ++k)
       if (ij[k] >= 0)
         small_block_products(B[k], ij[k] >> 16, ij[k] & 0xffff, zv, slot + (size_t)(tid + k * SMALL_THREADS) * SMALL_CSTRIDE);
+#ifdef DBG_SMALL_TIMING
+    const long long t1 = clock64();
+#endif
     __syncthreads();
+#ifdef DBG_SMALL_TIMING
+    const long long t2 = clock64();
+#endif
     // (B) w = S z gathered per row; gamma = r.z, delta = z.w in one reduction
     double w[SMALL_VPT], pg = 0.0, pd = 0.0;
 #pragma unroll
@@ -1110,26 +1123,41 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
         pd += w[v] * z[v];
       }
     }
+#ifdef DBG_SMALL_TIMING
+    const long long t3 = clock64();
+#endif
     pg = wave_sum_dpp(pg);
     pd = wave_sum_dpp(pd);
     if (lane == 0) { red[2 * wv] = pg; red[2 * wv + 1] = pd; }
+#ifdef DBG_SMALL_TIMING
+    const long long t4 = clock64();
+#endif
     __syncthreads();
-    gamma = 0.0;
-    double delta = 0.0;
-#pragma unroll
-    for (int k = 0; k < SMALL_THREADS / 64; ++k) { gamma += red[2 * k]; delta += red[2 * k + 1]; }
+#ifdef DBG_SMALL_TIMING
+    const long long t5 = clock64();
+#endif
+    {
+      const double g01 = red[0] + red[2], g23 = red[4] + red[6], g45 = red[8] + red[10], g67 = red[12] + red[14];
+      const double d01 = red[1] + red[3], d23 = red[5] + red[7], d45 = red[9] + red[11], d67 = red[13] + red[15];
+      gamma = (g01 + g23) + (g45 + g67);
+      delta_ = (d01 + d23) + (d45 + d67);
+    }
     if (it == 0) gamma0 = gamma;
 #ifdef DBG_SMALL_FIXED
     if (it >= 32) break;
 #else
     if (it >= max_iter || !(gamma > tol2 * gamma0) || !(gamma > 0.0)) break;
 #endif
-    const double beta = it ? gamma / gamma_old : 0.0;
-    const double denom = it ? delta - beta * gamma / alpha_old : delta;
+    // beta = gamma / gamma_old; alpha = gamma / (delta - beta gamma / alpha_old) = gamma / (delta - beta^2 denom_old):
+    // one reciprocal on the critical path, 1 / gamma for the next iteration computed beside it
+    const double beta = it ? gamma * inv_gamma_old : 0.0;
+    const double denom = it ? delta_ - beta * beta * denom_old : delta_;
 #ifndef DBG_SMALL_FIXED
     if (!(denom > 0.0)) break;
 #endif
-    const double alpha = gamma / denom;
+    const double alpha = gamma * fast_rcp(denom);
+    inv_gamma_old = fast_rcp(gamma);
+    denom_old = denom;
     // (C) p = z + beta p; s = w + beta s (= S p); x += alpha p; r -= alpha s; z = Minv r
 #pragma unroll
     for (int v = 0; v < SMALL_VPT; ++v)
@@ -1142,11 +1170,22 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
       }
     __builtin_amdgcn_wave_barrier();  // the 6 rows of a camera belong to this wave: LDS keeps a wave's accesses in order
     precondition();
-    gamma_old = gamma;
-    alpha_old = alpha;
     ++it;
+#ifdef DBG_SMALL_TIMING
+    const long long t7 = clock64();
+#endif
     __syncthreads();
+#ifdef DBG_SMALL_TIMING
+    const long long t8 = clock64();
+    dbgT[0] += t1 - t0; dbgT[1] += t2 - t1; dbgT[2] += t3 - t2; dbgT[3] += t4 - t3; dbgT[4] += t5 - t4;
+    dbgT[5] += t6 - t5; dbgT[6] += t7 - t6; dbgT[7] += t8 - t7;
+#endif
   }
+#ifdef DBG_SMALL_TIMING
+  if (lane == 0 && it > 0)
+    printf("wave %d it %d: products %lld bar %lld | gather %lld wavesum %lld bar %lld | scalars %lld | update+precond %lld bar %lld\n",
+           wv, it, dbgT[0] / it, dbgT[1] / it, dbgT[2] / it, dbgT[3] / it, dbgT[4] / it, dbgT[5] / it, dbgT[6] / it, dbgT[7] / it);
+#endif
 #pragma unroll
   for (int v = 0; v < SMALL_VPT; ++v)
     if (ent[v] >= 0) d.dc[ent[v]] = x[v];
@@ -1159,18 +1198,11 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_pose_update: trial poses = retract(poses, dc); camera part of the step statistics
-// (g.d, d^T U d, |d|^2, |x|^2).  One thread per camera.
-__global__ __launch_bounds__(256) void k_pose_update(DeviceProblem d, const double* __restrict__ poses,
-                                                     double* __restrict__ poses_t) {
-  __shared__ double red[4];
-  if (poses == nullptr) {
-    const LmCtrl* c = d.ctrl;
-    if (c->done) return;
-    poses = d.poses_buf[c->sel];
-    poses_t = d.poses_buf[c->sel ^ 1];
-  }
-  const int cam = blockIdx.x * blockDim.x + threadIdx.x;
+// pose update: trial poses = retract(poses, dc); camera part of the step statistics
+// (g.d, d^T U d, |d|^2, |x|^2).  One thread per camera; runs as the trailing blocks of k_backsub.
+__device__ __forceinline__ void pose_update_block(const DeviceProblem& d, const double* __restrict__ poses,
+                                                  double* __restrict__ poses_t, int cam_block, double* red /*[4]*/) {
+  const int cam = cam_block * 256 + threadIdx.x;
   double gd = 0.0, dhd = 0.0, dn = 0.0, xn = 0.0, gmax = 0.0;
   if (cam < d.C) {
     const int f = d.cam2free[cam];
@@ -1217,6 +1249,18 @@ __global__ __launch_bounds__(256) void k_pose_update(DeviceProblem d, const doub
   }
 }
 
+__global__ __launch_bounds__(256) void k_pose_update(DeviceProblem d, const double* __restrict__ poses,
+                                                     double* __restrict__ poses_t) {
+  __shared__ double red[4];
+  if (poses == nullptr) {
+    const LmCtrl* c = d.ctrl;
+    if (c->done) return;
+    poses = d.poses_buf[c->sel];
+    poses_t = d.poses_buf[c->sel ^ 1];
+  }
+  pose_update_block(d, poses, poses_t, blockIdx.x, red);
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_backsub: dp_j = -Vd_j^-1 (gp_j + sum_k W_k^T dc_cam(k)),  trial point = P_j + dp_j, and the
 // point part of the step statistics (g.d, d^T V d + 2 dc^T W dp, |d|^2, |x|^2).
@@ -1225,7 +1269,8 @@ __global__ __launch_bounds__(256) void k_pose_update(DeviceProblem d, const doub
 template <int G>
 __global__ __launch_bounds__(256) void k_backsub(DeviceProblem d, double lam, double min_diag,
                                                  const double* __restrict__ pts, double* __restrict__ pts_t,
-                                                 int lm_per_group) {
+                                                 int lm_per_group, const double* __restrict__ poses,
+                                                 double* __restrict__ poses_t, int pose_blocks) {
   __shared__ double red[4];
   if (lam < 0.0) {
     const LmCtrl* c = d.ctrl;
@@ -1233,6 +1278,13 @@ __global__ __launch_bounds__(256) void k_backsub(DeviceProblem d, double lam, do
     lam = c->lam;
     pts = d.pts_buf[c->sel];
     pts_t = d.pts_buf[c->sel ^ 1];
+    poses = d.poses_buf[c->sel];
+    poses_t = d.poses_buf[c->sel ^ 1];
+  }
+  // the last pose_blocks blocks of the grid retract the poses (k_pose_update's work, no launch of its own)
+  if ((int)blockIdx.x >= (int)gridDim.x - pose_blocks) {
+    pose_update_block(d, poses, poses_t, blockIdx.x - (gridDim.x - pose_blocks), red);
+    return;
   }
   const int lane = threadIdx.x & (G - 1);
   const long group = ((long)blockIdx.x * blockDim.x + threadIdx.x) / G;

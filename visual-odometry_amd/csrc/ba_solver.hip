@@ -240,17 +240,18 @@ void launch_linearize(ba_handle* h, const double* poses, const double* pts) {
 }
 
 // lam < 0: solver mode
-void launch_backsub(ba_handle* h, double lam, const double* pts, double* pts_t) {
+void launch_backsub(ba_handle* h, double lam, const double* pts, double* pts_t, const double* poses, double* poses_t) {
   const DeviceProblem& d = h->d;
   const int G = h->g_lin, lpg = h->lpg_back;
   const long groups = (d.L_obs + lpg - 1) / lpg;
-  const int grid = grid_for(groups * G);
+  const int pb = grid_for(d.C);  // trailing blocks: pose retraction + camera step statistics
+  const int grid = grid_for(groups * G) + pb;
   const double md = h->opt.min_diag;
   switch (G) {
-    case 8: launch_timed(h, KT_BACKSUB, k_backsub<8>, grid, 256, d, lam, md, pts, pts_t, lpg); break;
-    case 16: launch_timed(h, KT_BACKSUB, k_backsub<16>, grid, 256, d, lam, md, pts, pts_t, lpg); break;
-    case 32: launch_timed(h, KT_BACKSUB, k_backsub<32>, grid, 256, d, lam, md, pts, pts_t, lpg); break;
-    default: launch_timed(h, KT_BACKSUB, k_backsub<64>, grid, 256, d, lam, md, pts, pts_t, lpg); break;
+    case 8: launch_timed(h, KT_BACKSUB, k_backsub<8>, grid, 256, d, lam, md, pts, pts_t, lpg, poses, poses_t, pb); break;
+    case 16: launch_timed(h, KT_BACKSUB, k_backsub<16>, grid, 256, d, lam, md, pts, pts_t, lpg, poses, poses_t, pb); break;
+    case 32: launch_timed(h, KT_BACKSUB, k_backsub<32>, grid, 256, d, lam, md, pts, pts_t, lpg, poses, poses_t, pb); break;
+    default: launch_timed(h, KT_BACKSUB, k_backsub<64>, grid, 256, d, lam, md, pts, pts_t, lpg, poses, poses_t, pb); break;
   }
 }
 
@@ -352,9 +353,7 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
 
 // step statistics + trial state + trial cost (all arguments null / negative: solver mode)
 void enqueue_trial(ba_handle* h, double lam, const double* poses, const double* pts, double* poses_t, double* pts_t) {
-  DeviceProblem& d = h->d;
-  k_pose_update<<<grid_for(d.C), 256, 0, h->stream>>>(d, poses, poses_t);
-  launch_backsub(h, lam, pts, pts_t);
+  launch_backsub(h, lam, pts, pts_t, poses, poses_t);
   launch_cost(h, poses_t, pts_t, SC_COST_T, SC_NBEHIND_T, nullptr);
 }
 
