@@ -762,16 +762,22 @@ __global__ __launch_bounds__(256) void k_gather_S(DeviceProblem d, int solver_mo
   double acc[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) acc[u] = 0.0;
-  if (lane < CTR_ROW) {
-    int r = r0 + w;
-    for (; r + 28 < r1; r += 32) {
-      long q[8];
+  // wave w takes rows r0 + w + 4 k.  Lane l first fetches the row number of k = kb + l (one load for 64
+  // rows), then the rows are read 16 at a time: no contribution load waits for an index load.
+  const int cnt = (r1 - r0 - w + 3) >> 2;  // rows of this wave
+  for (int kb = 0; kb < cnt; kb += 64) {
+    const int mine = (kb + lane < cnt) ? d.ctr_row[r0 + w + 4 * (kb + lane)] : 0;
+    const int m = min(64, cnt - kb);
+    for (int k0 = 0; k0 < m; k0 += 16) {
+      double v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) q[u] = d.ctr_row[r + 4 * u];
+      for (int u = 0; u < 16; ++u) {
+        const long q = __builtin_amdgcn_readlane(mine, (k0 + u) & 63);
+        v[u] = (k0 + u < m && lane < CTR_ROW) ? d.contrib[q * CTR_ROW + lane] : 0.0;
+      }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc[u] += d.contrib[q[u] * CTR_ROW + lane];
+      for (int u = 0; u < 16; ++u) acc[u & 7] += v[u];
     }
-    for (; r < r1; r += 4) acc[0] += d.contrib[(long)d.ctr_row[r] * CTR_ROW + lane];
   }
   part[w][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   __syncthreads();
