@@ -51,10 +51,11 @@ typedef enum { BA_SOLVER_AUTO = 0, BA_SOLVER_PCG = 1, BA_SOLVER_DENSE_CHOLESKY =
 
 /* Solver settings.  The reference hard-codes its settings as literals in the least_squares call
  * (bundle_adjustment.py:201-212: ftol = xtol = gtol = 1e-6, max_nfev = 2000); defaults here are
- * tighter so that the converged cost is at or below the reference's. */
+ * tighter (ftol = scipy's own default) so that the converged cost is at or below the reference's
+ * (SURVEY.md section 7). */
 typedef struct {
   int32_t max_iters;        /* LM iterations (linearisations), default 200 */
-  double ftol;              /* stop when an accepted step lowers the cost by <= ftol * cost; 1e-10 */
+  double ftol;              /* stop when an accepted step lowers the cost by <= ftol * cost; 1e-8 */
   double xtol;              /* stop when |step| <= xtol * (xtol + |x|); 1e-12 */
   double gtol;              /* stop when |J^T r|_inf <= gtol; 1e-10 */
   double lambda0;           /* initial LM damping (Marquardt-scaled), 1e-4 */
@@ -64,7 +65,7 @@ typedef struct {
   double accept_ratio;      /* accept a step when actual/predicted decrease > this, 1e-4 */
   int32_t guard_cheirality; /* reject a step that moves more observations behind their camera, 1 */
   int32_t linear_solver;    /* ba_linear_solver, default BA_SOLVER_AUTO */
-  double pcg_tol;           /* relative residual (M^-1 norm) at which block-Jacobi PCG stops, 1e-2 */
+  double pcg_tol;           /* relative residual (M^-1 norm) at which block-Jacobi PCG stops, 3e-2 */
   int32_t pcg_max_iter;     /* 1000 */
   int32_t pcg_check_every;  /* PCG iterations between host polls of the device-side stop flag, 10 */
   int32_t lm_check_every;   /* LM iterations enqueued between host polls of the device-side LM state, 2 */

@@ -38,7 +38,7 @@ def test_defaults():
     lib = _native.load_library()
     o = _native.BaOptions()
     lib.ba_default_options(ctypes.byref(o))
-    assert o.max_iters == 200 and o.ftol == 1e-10 and o.lambda0 == 1e-4 and o.guard_cheirality == 1
+    assert o.max_iters == 200 and o.ftol == 1e-8 and o.lambda0 == 1e-4 and o.guard_cheirality == 1
 
 
 def test_no_gpu_fails_loudly():

@@ -515,7 +515,7 @@ int ba_device_count(void) {
 void ba_default_options(ba_options* o) {
   if (!o) return;
   o->max_iters = 200;
-  o->ftol = 1e-10;
+  o->ftol = 1e-8;
   o->xtol = 1e-12;
   o->gtol = 1e-10;
   o->lambda0 = 1e-4;
@@ -525,7 +525,7 @@ void ba_default_options(ba_options* o) {
   o->accept_ratio = 1e-4;
   o->guard_cheirality = 1;
   o->linear_solver = BA_SOLVER_AUTO;
-  o->pcg_tol = 1e-2;
+  o->pcg_tol = 3e-2;
   o->pcg_max_iter = 1000;
   o->pcg_check_every = 10;
   o->lm_check_every = 2;
