@@ -139,6 +139,23 @@ int ba_upload_guess(ba_handle* h, const double* poses, const double* points);
 int ba_solve_resident(ba_handle* h, ba_report* report);
 int ba_download_estimate(ba_handle* h, double* poses, double* points);
 
+/* Batched local bundle adjustment (BASELINE.json configs[4]: thousands of independent windows of
+ * ~10 keyframes; SURVEY.md section 8b "solve_batched(B problems, offsets)").  The reference would call
+ * BundleAdjustment.optimize (bundle_adjustment.py:156-163) once per window from its keyframe list
+ * (visual_odometry.py:268-277 keeps the keyframes; the call itself is missing there).  Problem b owns
+ * cameras [cam_off[b], cam_off[b+1]), landmarks [lm_off[b], lm_off[b+1]) and observations
+ * [obs_off[b], obs_off[b+1]); obs_cam / obs_pt are indices LOCAL to the observation's problem; the
+ * first camera of every problem is held fixed; one camera model for all.  poses[cam_off[B]*7] and
+ * points[lm_off[B]*3] are in/out.  All windows are solved together as one block-diagonal problem
+ * (one LM damping sequence and one accept/reject decision for the batch; the reduced camera system
+ * is solved exactly, one dense Cholesky per window).  cost0 / cost (may be NULL) receive each
+ * problem's 0.5 * sum r^2 before / after; report (may be NULL) describes the batch.  Leaves the
+ * handle set to the concatenated problem. */
+int ba_solve_batched(ba_handle* h, int32_t n_problems, const int32_t* cam_off, const int32_t* lm_off,
+                     const int32_t* obs_off, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv,
+                     const double* intrinsics, double* poses, double* points, double* cost0, double* cost,
+                     ba_report* report);
+
 /* Residual vector and cost at (poses, points), residuals[2*n_obs] in the caller's observation
  * order ([u0, v0, u1, v1, ...]); residuals may be NULL.  Replaces
  * BundleAdjustment.residual_function (bundle_adjustment.py:20-87).  n_behind (may be NULL) receives

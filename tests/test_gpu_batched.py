@@ -1,0 +1,102 @@
+"""GPU tests of the batched local bundle adjustment (ba_solve_batched, BASELINE config 5) and of the
+dense Cholesky linear solver it uses (k_solve_components), through the C ABI."""
+
+import numpy as np
+import pytest
+
+import scenes
+from oracle import lm_schur_numpy as lm
+from src import _native
+from src.validation_error import ValidationError
+
+pytestmark = pytest.mark.gpu
+
+
+def _window(seed, K=10, L=120):
+    sc = scenes.local_window_scene(seed, K=K, L=L)
+    return dict(obs_cam=sc["obs_cam"], obs_pt=sc["obs_pt"], obs_uv=sc["obs_uv"], poses=sc["poses_guess"],
+                points=sc["points_guess"]), sc
+
+
+def test_dense_cholesky_step_matches_oracle(golden):
+    """linear_solver = dense Cholesky: the LM step of one linearisation against numpy's dense solve of the
+    oracle's reduced system (exact solver, so 1e-9 relative instead of the PCG test's 1e-7)."""
+    g = golden("noisy_10x300")
+    n_poses = len(g["poses_gt"]) - 1
+    poses = np.vstack([g["pose0"][None], g["x0"][: 7 * n_poses].reshape(-1, 7)])
+    pts = g["x0"][7 * n_poses:].reshape(-1, 3)
+    C, L, lam = n_poses + 1, len(pts), 1e-3
+    with _native.Solver(linear_solver=2) as s:
+        s.set_problem(C, L, g["obs_cam"], g["obs_pt"], g["obs_uv"], g["intr"])
+        out = s.debug_linearization(poses, pts, lam)
+    r, Jc, Jp = lm.linearize(poses, pts, g["obs_cam"], g["obs_pt"], g["obs_uv"], g["intr"])
+    free = np.ones(C, bool)
+    free[0] = False
+    Jc = Jc * free[g["obs_cam"]][:, None, None]
+    U, V, W, gc, gp, _ = lm.normal_blocks(r, Jc, Jp, g["obs_cam"], g["obs_pt"], C, L)
+    S, rhs, Vi = lm.schur_system(U, V, W, gc, gp, g["obs_cam"], g["obs_pt"], lam, free)
+    dc = np.linalg.solve(S, -rhs).reshape(C, 6) * free[:, None]
+    dp = lm.back_substitute(dc, Vi, W, gp, g["obs_cam"], g["obs_pt"], L)
+    np.testing.assert_allclose(out["dc"], dc, rtol=0, atol=1e-9 * np.abs(dc).max())
+    np.testing.assert_allclose(out["dp"], dp, rtol=0, atol=1e-9 * np.abs(dp).max())
+
+
+def test_dense_cholesky_converges_like_pcg(golden):
+    g = golden("noisy_10x300")
+    n_poses = len(g["poses_gt"]) - 1
+    poses = np.vstack([g["pose0"][None], g["x0"][: 7 * n_poses].reshape(-1, 7)])
+    pts = g["x0"][7 * n_poses:].reshape(-1, 3)
+    with _native.Solver(linear_solver=2) as s:
+        s.set_problem(n_poses + 1, len(pts), g["obs_cam"], g["obs_pt"], g["obs_uv"], g["intr"])
+        _, _, rep = s.solve(poses, pts)
+    pol = float(g["polished_cost"])
+    assert rep["pcg_iters"] == 0
+    assert abs(rep["cost"] - pol) <= 1e-6 * pol
+
+
+def test_dense_cholesky_refuses_large_components():
+    sc = scenes.ring_scene(50, 2000, 10)
+    with _native.Solver(linear_solver=2) as s:
+        with pytest.raises(ValidationError):
+            s.set_problem(50, 2000, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+
+
+def test_batched_windows_match_individual_solves():
+    """B independent windows solved as one block-diagonal problem: every window must land on the minimum
+    that its own solve finds (1e-6 relative in cost, north_star's bar), which the oracle's LM confirms for
+    the first one; poses / points agree after the solve to 1e-5."""
+    seeds = [0, 1, 2, 3, 4, 5, 6]
+    sizes = [120, 80, 200, 120, 100, 150, 90]  # ragged batch
+    probs, scs = zip(*[_window(s, L=l) for s, l in zip(seeds, sizes)])
+    intr = scs[0]["intr"]
+    with _native.Solver() as s:
+        P, X, cost0, cost, rep = s.solve_batched(probs, intr)
+    assert rep["pcg_iters"] == 0 and rep["status"] in (1, 2, 3)
+    assert abs(cost.sum() - rep["cost"]) <= 1e-10 * rep["cost"]
+    assert abs(cost0.sum() - rep["cost0"]) <= 1e-10 * rep["cost0"]
+    for b, (p, sc) in enumerate(zip(probs, scs)):
+        with _native.Solver() as s1:
+            s1.set_problem(len(p["poses"]), len(p["points"]), p["obs_cam"], p["obs_pt"], p["obs_uv"], intr)
+            P1, X1, rep1 = s1.solve(p["poses"], p["points"])
+        assert abs(cost[b] - rep1["cost"]) <= 1e-6 * rep1["cost"], (b, cost[b], rep1["cost"])
+        assert abs(cost0[b] - rep1["cost0"]) <= 1e-12 * rep1["cost0"]
+        np.testing.assert_array_equal(P[b][0], np.asarray(p["poses"])[0])  # first camera of a window is fixed
+        # monocular scale about camera 0 is a free gauge direction: compare after aligning it
+        sc1 = np.linalg.norm(X1 - P1[0, :3]) / np.linalg.norm(X[b] - P[b][0, :3])
+        np.testing.assert_allclose(P[b][:, :3] * sc1, P1[:, :3], atol=1e-5 * max(1.0, np.abs(P1[:, :3]).max()))
+        np.testing.assert_allclose(X[b] * sc1, X1, atol=1e-5 * np.abs(X1).max())
+    # the oracle's LM (numpy, exact reduced solve) on window 0
+    p, sc = probs[0], scs[0]
+    o = lm.lm_solve(np.asarray(p["poses"]), np.asarray(p["points"]), p["obs_cam"], p["obs_pt"], p["obs_uv"], intr)
+    cost_o = o[2].cost
+    assert abs(cost[0] - cost_o) <= 1e-6 * cost_o
+
+
+def test_batched_rejects_bad_input():
+    probs, scs = zip(*[_window(s) for s in (0, 1)])
+    bad = dict(probs[1])
+    bad["obs_cam"] = np.asarray(bad["obs_cam"]).copy()
+    bad["obs_cam"][3] = 99  # camera index outside its window
+    with _native.Solver() as s:
+        with pytest.raises(ValidationError):
+            s.solve_batched([probs[0], bad], scs[0]["intr"])

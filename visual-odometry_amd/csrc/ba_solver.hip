@@ -79,6 +79,8 @@ struct ba_handle {
   int g_lin = 16, g_schur = 64, lpg_lin = 1, lpg_schur = 1, lpg_back = 1;
   int schur_cpb = 0;  // > 0: k_schur_staged with this many chunks per block
   bool small_solve = false, small_cached = false;
+  bool comp_solve = false;  // dense Cholesky per connected component of the camera graph
+  size_t comp_lds = 0;
   size_t small_lds = 0;
 
   DeviceProblem d{};
@@ -314,6 +316,12 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
   if (h->world > 1)  // the one exchange step of the path: partial S, reduced rhs, U / gc summed over the shards
     NCCL_TRY(h, h->rccl->AllReduce(d.S, d.S, red_count, ncclDouble, ncclSum, h->comm, h->stream));
   const double tol2 = o.pcg_tol * o.pcg_tol;
+  if (h->comp_solve) {
+    k_solve_components<<<d.n_comp, 64, h->comp_lds, h->stream>>>(d, lam, o.min_diag);
+    *pcg_iters = -1;
+    if (h->world > 1) NCCL_TRY(h, h->rccl->Broadcast(d.dc, d.dc, (size_t)6 * d.Cf, ncclDouble, 0, h->comm, h->stream));
+    return BA_OK;
+  }
   if (h->small_solve) {
     k_block_precond<<<grid_for(d.Cf, 64), 64, 0, h->stream>>>(d, lam, o.min_diag);
     if (d.nu <= SMALL_THREADS)
@@ -435,7 +443,7 @@ int lm_solve(ba_handle* h, ba_report* rep) {
   HIP_TRY(h, hipMemcpyAsync(d.pts_buf[0], h->pts_init, pts_bytes, hipMemcpyDeviceToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(d.pts_buf[1], h->pts_init, pts_bytes, hipMemcpyDeviceToDevice, h->stream));
 
-  const int check_every = h->small_solve ? std::max(1, o.lm_check_every) : 1;
+  const int check_every = (h->small_solve || h->comp_solve) ? std::max(1, o.lm_check_every) : 1;
   const size_t head_bytes = sizeof(LmHead);
   int enq = 0, rc;
   bool done = false;
@@ -933,6 +941,47 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
     }
   }
 
+  // connected components of the camera graph -> dense Cholesky per component when all are small
+  std::vector<int> comp_ptr(1, 0), comp_cams(Cf), comp_local(Cf), comp_slot_ptr(1, 0), comp_slots(nu);
+  {
+    std::vector<int> parent(Cf);
+    std::iota(parent.begin(), parent.end(), 0);
+    auto find = [&](int a) { while (parent[a] != a) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; };
+    for (int s2 = 0; s2 < nu; ++s2) {
+      const int a = find(urow[s2]), b = find(ucol[s2]);
+      if (a != b) parent[std::max(a, b)] = std::min(a, b);
+    }
+    std::vector<int> comp_id(Cf, -1), count;
+    for (int f = 0; f < Cf; ++f) {  // roots are the smallest camera of a component: ids ascend with the cameras
+      const int r = find(f);
+      if (comp_id[r] < 0) { comp_id[r] = (int)count.size(); count.push_back(0); }
+      comp_id[f] = comp_id[r];
+      comp_local[f] = count[comp_id[f]]++;
+    }
+    const int n_comp = (int)count.size();
+    int max_cams = 0;
+    for (int c = 0; c < n_comp; ++c) { comp_ptr.push_back(comp_ptr.back() + count[c]); max_cams = std::max(max_cams, count[c]); }
+    for (int f = 0; f < Cf; ++f) comp_cams[comp_ptr[comp_id[f]] + comp_local[f]] = f;
+    std::vector<int> scount(n_comp, 0);
+    for (int s2 = 0; s2 < nu; ++s2) scount[comp_id[urow[s2]]]++;
+    for (int c = 0; c < n_comp; ++c) comp_slot_ptr.push_back(comp_slot_ptr.back() + scount[c]);
+    std::vector<int> fill(comp_slot_ptr.begin(), comp_slot_ptr.end() - 1);
+    for (int s2 = 0; s2 < nu; ++s2) comp_slots[fill[comp_id[urow[s2]]]++] = s2;
+    h->d.n_comp = n_comp;
+    const int n = 6 * max_cams;
+    h->comp_lds = ((size_t)n * (n + 1) + n) * sizeof(double);
+    const int want = h->opt.linear_solver;
+    // AUTO: several components (batched windows) -> Cholesky; one small component keeps the PCG path unless asked
+    h->comp_solve = Cf > 0 && max_cams <= COMP_MAX_CAMS && env_int("BA_COMP_SOLVE", 1) &&
+                    (want == BA_SOLVER_DENSE_CHOLESKY || (want == BA_SOLVER_AUTO && n_comp > 1));
+    if (want == BA_SOLVER_DENSE_CHOLESKY && !h->comp_solve)
+      return fail(h, BA_ERR_INVALID, "dense Cholesky needs connected camera groups of at most %d free cameras (largest here: %d)",
+                  COMP_MAX_CAMS, max_cams);
+    if (h->comp_solve && h->comp_lds > 32 * 1024)
+      HIP_TRY(h, hipFuncSetAttribute((const void*)k_solve_components, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)h->comp_lds));
+  }
+
   // ---- upload structure, allocate state
   std::vector<int> fixed_cams;
   for (int c = 0; c < C; ++c)
@@ -954,6 +1003,9 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
       (rc = dev_upload(h, &d.brow_ptr, brow_ptr)) || (rc = dev_upload(h, &d.bcol, bcol)) ||
       (rc = dev_upload(h, &d.bslot, bslot)) || (rc = dev_upload(h, &d.sm_slot, sm_slot)) ||
       (rc = dev_upload(h, &d.sm_gidx, sm_gidx)) ||
+      (rc = dev_upload(h, &d.comp_ptr, comp_ptr)) || (rc = dev_upload(h, &d.comp_cams, comp_cams)) ||
+      (rc = dev_upload(h, &d.comp_local, comp_local)) || (rc = dev_upload(h, &d.comp_slot_ptr, comp_slot_ptr)) ||
+      (rc = dev_upload(h, &d.comp_slots, comp_slots)) ||
       (rc = dev_upload(h, &d.sch_lm, sch_lm)) || (rc = dev_upload(h, &d.sch_k, sch_k)) ||
       (rc = dev_upload(h, &d.sch_flush, sch_flush)) || (rc = dev_upload(h, &d.sch_blk_row, sch_blk_row)) ||
       (rc = dev_upload(h, &d.ctr_ptr, ctr_ptr)) || (rc = dev_upload(h, &d.ctr_row, ctr_row)) ||
@@ -1024,6 +1076,53 @@ int ba_solve(ba_handle* h, double* poses, double* points, ba_report* report) {
   if (rc) return rc;
   if ((rc = ba_solve_resident(h, report))) return rc;
   return ba_download_estimate(h, poses, points);
+}
+
+int ba_solve_batched(ba_handle* h, int32_t B, const int32_t* cam_off, const int32_t* lm_off, const int32_t* obs_off,
+                     const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv, const double* intr,
+                     double* poses, double* points, double* cost0, double* cost, ba_report* report) {
+  if (!h) return BA_ERR_INVALID;
+  if (B <= 0 || !cam_off || !lm_off || !obs_off || !obs_cam || !obs_pt || !obs_uv || !intr || !poses || !points)
+    return fail(h, BA_ERR_INVALID, "solve_batched: empty batch or null pointer");
+  if (cam_off[0] != 0 || lm_off[0] != 0 || obs_off[0] != 0)
+    return fail(h, BA_ERR_INVALID, "solve_batched: offset arrays must start at 0");
+  for (int b = 0; b < B; ++b)
+    if (cam_off[b + 1] <= cam_off[b] || lm_off[b + 1] <= lm_off[b] || obs_off[b + 1] <= obs_off[b])
+      return fail(h, BA_ERR_INVALID, "solve_batched: problem %d is empty or its offsets decrease", b);
+  const int C = cam_off[B], L = lm_off[B], n = obs_off[B];
+  // One block-diagonal problem: global indices, the first camera of every window fixed.  The windows
+  // share no camera and no landmark, so the camera graph falls into >= B components and the reduced
+  // system is solved by one dense Cholesky per component (k_solve_components).
+  std::vector<int32_t> gcam(n), gpt(n);
+  std::vector<uint8_t> fixed(C, 0);
+  for (int b = 0; b < B; ++b) {
+    fixed[cam_off[b]] = 1;
+    const int nc = cam_off[b + 1] - cam_off[b], nl = lm_off[b + 1] - lm_off[b];
+    for (int k = obs_off[b]; k < obs_off[b + 1]; ++k) {
+      if (obs_cam[k] < 0 || obs_cam[k] >= nc || obs_pt[k] < 0 || obs_pt[k] >= nl)
+        return fail(h, BA_ERR_INVALID, "solve_batched: observation %d of problem %d has an index out of range", k - obs_off[b], b);
+      gcam[k] = cam_off[b] + obs_cam[k];
+      gpt[k] = lm_off[b] + obs_pt[k];
+    }
+  }
+  int rc = ba_set_problem(h, C, L, n, gcam.data(), gpt.data(), obs_uv, intr, fixed.data());
+  if (rc) return rc;
+  std::vector<double> res;
+  auto per_problem = [&](double* out) -> int {
+    res.resize((size_t)2 * n);
+    int rc2 = ba_evaluate(h, poses, points, res.data(), nullptr, nullptr);
+    if (rc2) return rc2;
+    for (int b = 0; b < B; ++b) {
+      double acc = 0.0;
+      for (size_t k = (size_t)2 * obs_off[b]; k < (size_t)2 * obs_off[b + 1]; ++k) acc += res[k] * res[k];
+      out[b] = 0.5 * acc;
+    }
+    return BA_OK;
+  };
+  if (cost0 && (rc = per_problem(cost0))) return rc;
+  if ((rc = ba_solve(h, poses, points, report))) return rc;
+  if (cost && (rc = per_problem(cost))) return rc;
+  return BA_OK;
 }
 
 int ba_evaluate(ba_handle* h, const double* poses, const double* points, double* residuals, double* cost,
@@ -1129,7 +1228,7 @@ int ba_debug_linearization(ba_handle* h, const double* poses, const double* poin
   }
   if (S) {
     if ((rc = fetch(t, d.S, (size_t)36 * d.nu))) return rc;
-    if (h->small_solve) {  // the one-workgroup solve applies the damping on the fly; add it for the export
+    if (h->small_solve || h->comp_solve) {  // these solvers apply the damping on the fly; add it for the export
       std::vector<double> ugc, ud((size_t)6 * Cf);
       if ((rc = fetch(ugc, d.Ugc, (size_t)27 * C))) return rc;
       for (int f = 0; f < Cf; ++f)

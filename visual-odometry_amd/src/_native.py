@@ -68,6 +68,7 @@ _SIGNATURES = {
     "ba_upload_guess": (C.c_int, [_P, _D, _D]),
     "ba_solve_resident": (C.c_int, [_P, C.POINTER(BaReport)]),
     "ba_download_estimate": (C.c_int, [_P, _D, _D]),
+    "ba_solve_batched": (C.c_int, [_P, C.c_int32, _I, _I, _I, _I, _I, _D, _D, _D, _D, _D, _D, C.POINTER(BaReport)]),
     "ba_evaluate": (C.c_int, [_P, _D, _D, _D, _D, _I]),
     "ba_jacobian_blocks": (C.c_int, [_P, _D, _D, _D, _D]),
     "ba_debug_linearization": (C.c_int, [_P, _D, _D, C.c_double] + [_D] * 9),
@@ -205,6 +206,39 @@ class Solver:
         rep = BaReport()
         self._check(self._lib.ba_solve_resident(self._h, C.byref(rep)))
         return rep.as_dict()
+
+    def solve_batched(self, problems, intr):
+        """Batched local bundle adjustment (ba_solve_batched): `problems` is a sequence of dicts with
+        obs_cam / obs_pt (indices local to the problem), obs_uv, poses (Cb x 7, row 0 fixed) and points
+        (Lb x 3).  Returns (list of poses, list of points, cost0[B], cost[B], report)."""
+        B = len(problems)
+        if B == 0:
+            raise ValidationError("solve_batched needs at least one problem")
+        cam_off = np.zeros(B + 1, np.int32)
+        lm_off = np.zeros(B + 1, np.int32)
+        obs_off = np.zeros(B + 1, np.int32)
+        for b, p in enumerate(problems):
+            cam_off[b + 1] = cam_off[b] + len(p["poses"])
+            lm_off[b + 1] = lm_off[b] + len(p["points"])
+            obs_off[b + 1] = obs_off[b] + len(p["obs_cam"])
+        obs_cam = np.ascontiguousarray(np.concatenate([np.asarray(p["obs_cam"]) for p in problems]), dtype=np.int32)
+        obs_pt = np.ascontiguousarray(np.concatenate([np.asarray(p["obs_pt"]) for p in problems]), dtype=np.int32)
+        obs_uv = _f64(np.concatenate([np.asarray(p["obs_uv"], dtype=np.float64).reshape(-1, 2) for p in problems]))
+        poses = _f64(np.concatenate([_f64(p["poses"]).reshape(-1, 7) for p in problems])).copy()
+        points = _f64(np.concatenate([_f64(p["points"]).reshape(-1, 3) for p in problems])).copy()
+        if len(obs_pt) != len(obs_cam) or len(obs_uv) != len(obs_cam):
+            raise ValidationError("obs_cam, obs_pt and obs_uv must have the same length in every problem")
+        intr = _f64(intr, (7,))
+        cost0 = np.empty(B)
+        cost = np.empty(B)
+        rep = BaReport()
+        ip = lambda a: a.ctypes.data_as(_I)
+        self._check(self._lib.ba_solve_batched(self._h, B, ip(cam_off), ip(lm_off), ip(obs_off), ip(obs_cam), ip(obs_pt),
+                                               _dptr(obs_uv), _dptr(intr), _dptr(poses), _dptr(points), _dptr(cost0),
+                                               _dptr(cost), C.byref(rep)))
+        self.C, self.L, self.n = int(cam_off[B]), int(lm_off[B]), int(obs_off[B])
+        return ([poses[cam_off[b]:cam_off[b + 1]] for b in range(B)], [points[lm_off[b]:lm_off[b + 1]] for b in range(B)],
+                cost0, cost, rep.as_dict())
 
     def download_estimate(self, poses, points):
         poses, points = self._state(poses, points)
