@@ -94,7 +94,7 @@ def main():
     C, L1, d = WORKLOADS[args.workload]
     L = L1 * world
     scene = scenes.ring_scene(C, L, d, seed=0)
-    solver = _native.Solver(device=local_rank, profile_kernels=0 if args.no_kernel_events else 1)
+    solver = _native.Solver(device=local_rank, profile_kernels=0)
     if world > 1:
         uid = [_native.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -119,7 +119,6 @@ def main():
 
     for _ in range(args.warmup):
         rep = solver.solve_resident()
-    k0 = solver.kernel_times()
     barrier()
     t0 = time.perf_counter()
     iters = 0
@@ -128,6 +127,14 @@ def main():
         iters += rep["iterations"]
     barrier()
     elapsed = time.perf_counter() - t0
+    # second pass, untimed: the same K solves with a start/stop event pair attached to every kernel launch
+    # (hipExtLaunchKernelGGL, on the solver's stream) for the per-kernel durations behind `roofline`
+    k0 = solver.kernel_times()
+    if not args.no_kernel_events:
+        solver.set_kernel_timing(True)
+        for _ in range(args.steps):
+            solver.solve_resident()
+        solver.set_kernel_timing(False)
     k1 = solver.kernel_times()
 
     units = float(nobs) * iters
@@ -144,14 +151,23 @@ def main():
         ktimes = {k: ((k1[k][0] - k0[k][0]), (k1[k][1] - k0[k][1])) for k in k1}
         big = {k: v for k, v in ktimes.items() if k in ("k_linearize", "k_schur", "k_backsub", "k_cost") and v[1] > 0}
         roofline = None
+        traffic_db = {}
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath) and args.workload == "cfg2" and world == 1:
+            with open(tpath) as fh:  # HBM bytes per launch from rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py)
+                traffic_db = json.load(fh).get("kernels", {})
         if big:
             dom = max(big, key=lambda k: big[k][0])
             avg_ms = big[dom][0] / big[dom][1]
             bytes_launch = algorithmic_bytes(dom, nobs, L_local, C)
             ach = bytes_launch / (avg_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": avg_ms,
+                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic_db.get(dom, {}).get("traffic_bytes"),
+                        "avg_kernel_ms": avg_ms,
                         "algorithmic_bytes_per_launch": bytes_launch,
+                        "note": "dominant of the four HBM-streaming kernels; 'pcg' (the reduced camera solve, one "
+                                "workgroup, LDS/latency-bound, no HBM traffic in its loop) and 'other' (S gather, "
+                                "preconditioner, LM control) are listed in per_kernel without a bandwidth figure",
                         "per_kernel": {k: {"total_ms": v[0], "launches": v[1],
                                            "avg_us": 1e3 * v[0] / max(v[1], 1),
                                            "GBps": (algorithmic_bytes(k, nobs, L_local, C) / (v[0] / v[1] * 1e-3) / 1e9)

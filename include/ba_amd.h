@@ -185,6 +185,10 @@ int ba_debug_linearization(ba_handle* h, const double* poses, const double* poin
  * k_damp_mirror + k_pose_update + memsets.  No reference counterpart (bench.py's roofline figures). */
 #define BA_KERNEL_CLASSES 6
 int ba_get_kernel_times(ba_handle* h, double* total_ms, int32_t* launches);
+/* Switch the per-launch start/stop events (ba_options.profile_kernels) on or off for later solves.
+ * No counterpart in the reference; used by bench.py, which times the solves without events and then
+ * measures the kernels in a second pass. */
+int ba_set_kernel_timing(ba_handle* h, int32_t on);
 
 /* Multi-GPU (one process per GPU, landmark-sharded; no reference counterpart -- the reference is one
  * Python thread).  Rank 0 calls ba_comm_unique_id and ships the 128 bytes to the other ranks by any

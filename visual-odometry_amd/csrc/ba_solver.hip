@@ -218,14 +218,18 @@ inline int grid_for(long items, int block = 256) { return (int)std::max<long>(1,
 // start / stop events are attached to the launch itself, so the measured span is the kernel's execution
 // (agrees with rocprofv3's per-dispatch duration) and costs no extra API call.
 template <class... KArgs, class... Args>
-void launch_timed(ba_handle* h, int cls, void (*kern)(KArgs...), int grid, int block, Args... args) {
+void launch_timed_lds(ba_handle* h, int cls, void (*kern)(KArgs...), int grid, int block, size_t lds, Args... args) {
   if (h->opt.profile_kernels) {
     hipEvent_t a = next_event(h), b = next_event(h);
-    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, h->stream, a, b, 0, args...);
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, h->stream, a, b, 0, args...);
     h->spans.push_back({cls, a, b, h->span_iter});
   } else {
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, h->stream, args...);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, h->stream, args...);
   }
+}
+template <class... KArgs, class... Args>
+void launch_timed(ba_handle* h, int cls, void (*kern)(KArgs...), int grid, int block, Args... args) {
+  launch_timed_lds(h, cls, kern, grid, block, 0, args...);
 }
 
 // poses / pts == nullptr: solver mode (state and run/skip decision come from the device-side LM control)
@@ -310,24 +314,24 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
   const ba_options& o = h->opt;
   const int mode = lam < 0.0;
   launch_schur(h, lam);
-  if (h->schur_cpb > 0) k_gather_S<<<d.nu + (d.C - d.Cf), 256, 0, h->stream>>>(d, mode);
-  else k_reduce_S<<<grid_for(d.s_slab_stride + 27L * d.C), 256, 0, h->stream>>>(d, mode);
+  if (h->schur_cpb > 0) launch_timed(h, KT_OTHER, k_gather_S, d.nu + (d.C - d.Cf), 256, d, mode);
+  else launch_timed(h, KT_OTHER, k_reduce_S, grid_for(d.s_slab_stride + 27L * d.C), 256, d, mode);
   const size_t red_count = (size_t)d.nu * 36 + (size_t)6 * d.Cf + (size_t)27 * d.C;
   if (h->world > 1)  // the one exchange step of the path: partial S, reduced rhs, U / gc summed over the shards
     NCCL_TRY(h, h->rccl->AllReduce(d.S, d.S, red_count, ncclDouble, ncclSum, h->comm, h->stream));
   const double tol2 = o.pcg_tol * o.pcg_tol;
   if (h->comp_solve) {
-    k_solve_components<<<d.n_comp, 64, h->comp_lds, h->stream>>>(d, lam, o.min_diag);
+    launch_timed_lds(h, KT_PCG, k_solve_components, d.n_comp, 64, h->comp_lds, d, lam, o.min_diag);
     *pcg_iters = -1;
     if (h->world > 1) NCCL_TRY(h, h->rccl->Broadcast(d.dc, d.dc, (size_t)6 * d.Cf, ncclDouble, 0, h->comm, h->stream));
     return BA_OK;
   }
   if (h->small_solve) {
-    k_block_precond<<<grid_for(d.Cf, 64), 64, 0, h->stream>>>(d, lam, o.min_diag);
+    launch_timed(h, KT_OTHER, k_block_precond, grid_for(d.Cf, 64), 64, d, lam, o.min_diag);
     if (d.nu <= SMALL_THREADS)
-      k_solve_small<1><<<1, SMALL_THREADS, h->small_lds, h->stream>>>(d, lam, o.min_diag, tol2, o.pcg_max_iter);
+      launch_timed_lds(h, KT_PCG, k_solve_small<1>, 1, SMALL_THREADS, h->small_lds, d, lam, o.min_diag, tol2, o.pcg_max_iter);
     else
-      k_solve_small<2><<<1, SMALL_THREADS, h->small_lds, h->stream>>>(d, lam, o.min_diag, tol2, o.pcg_max_iter);
+      launch_timed_lds(h, KT_PCG, k_solve_small<2>, 1, SMALL_THREADS, h->small_lds, d, lam, o.min_diag, tol2, o.pcg_max_iter);
     *pcg_iters = -1;  // lives in scal[SC_PCGIT]
     // every rank solved the same system; ship rank 0's step so that all replicas of the poses stay
     // bit-identical (LDS atomics make the summation order, hence the last bits, rank-dependent)
@@ -465,9 +469,9 @@ int lm_solve(ba_handle* h, ba_report* rep) {
         NCCL_TRY(h, h->rccl->AllReduce(h->scal_fold + SC_COUNT, h->scal_fold + SC_COUNT, 1, ncclDouble, ncclMax,
                                        h->comm, h->stream));
         NCCL_TRY(h, h->rccl->GroupEnd());
-        k_lm_decide<<<1, 256, 0, h->stream>>>(d, h->scal_fold);
+        launch_timed(h, KT_OTHER, k_lm_decide, 1, 256, d, (const double*)h->scal_fold);
       } else {
-        k_lm_decide<<<1, 256, 0, h->stream>>>(d, nullptr);
+        launch_timed(h, KT_OTHER, k_lm_decide, 1, 256, d, (const double*)nullptr);
       }
     }
     HIP_TRY(h, hipMemcpyAsync(&c, d.ctrl, head_bytes, hipMemcpyDeviceToHost, h->stream));
@@ -584,6 +588,12 @@ const char* ba_last_error(const ba_handle* h) { return h ? h->err.c_str() : "nul
 int ba_get_kernel_times(ba_handle* h, double* total_ms, int32_t* launches) {
   if (!h || !total_ms || !launches) return BA_ERR_INVALID;
   for (int i = 0; i < BA_KERNEL_CLASSES; ++i) { total_ms[i] = h->ktime_ms[i]; launches[i] = h->kcount[i]; }
+  return BA_OK;
+}
+
+int ba_set_kernel_timing(ba_handle* h, int32_t on) {
+  if (!h) return BA_ERR_INVALID;
+  h->opt.profile_kernels = on ? 1 : 0;
   return BA_OK;
 }
 

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "ba_debug_linearization": (C.c_int, [_P, _D, _D, C.c_double] + [_D] * 9),
     "ba_schur_block_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "ba_get_kernel_times": (C.c_int, [_P, _D, _I]),
+    "ba_set_kernel_timing": (C.c_int, [_P, C.c_int32]),
     "ba_comm_unique_id": (C.c_int, [C.c_char_p]),
     "ba_comm_init": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_char_p]),
 }
@@ -279,6 +280,9 @@ class Solver:
         cnt = np.zeros(6, dtype=np.int32)
         self._check(self._lib.ba_get_kernel_times(self._h, _dptr(ms), cnt.ctypes.data_as(_I)))
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KERNEL_CLASSES)}
+
+    def set_kernel_timing(self, on: bool):
+        self._check(self._lib.ba_set_kernel_timing(self._h, 1 if on else 0))
 
     def schur_block_count(self) -> int:
         v = C.c_int64()
