@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lm-check-every", type=int, default=None, help="override ba_options.lm_check_every")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     args = ap.parse_args()
 
@@ -94,7 +95,8 @@ def main():
     C, L1, d = WORKLOADS[args.workload]
     L = L1 * world
     scene = scenes.ring_scene(C, L, d, seed=0)
-    solver = _native.Solver(device=local_rank, profile_kernels=0)
+    extra = {} if args.lm_check_every is None else {"lm_check_every": args.lm_check_every}
+    solver = _native.Solver(device=local_rank, profile_kernels=0, **extra)
     if world > 1:
         uid = [_native.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)

@@ -68,7 +68,7 @@ typedef struct {
   double pcg_tol;           /* relative residual (M^-1 norm) at which block-Jacobi PCG stops, 3e-2 */
   int32_t pcg_max_iter;     /* 1000 */
   int32_t pcg_check_every;  /* PCG iterations between host polls of the device-side stop flag, 10 */
-  int32_t lm_check_every;   /* LM iterations enqueued between host polls of the device-side LM state, 2 */
+  int32_t lm_check_every;   /* LM iterations enqueued between host polls of the device-side LM state, 1 */
   int32_t device;           /* HIP device ordinal; -1 = current device */
   int32_t verbose;          /* 1 = print one line per LM iteration to stderr */
   int32_t profile_kernels;  /* 1 = bracket every kernel class with HIP events (ba_get_kernel_times) */

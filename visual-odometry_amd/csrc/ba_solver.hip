@@ -540,7 +540,7 @@ void ba_default_options(ba_options* o) {
   o->pcg_tol = 3e-2;
   o->pcg_max_iter = 1000;
   o->pcg_check_every = 10;
-  o->lm_check_every = 2;
+  o->lm_check_every = 1;
   o->device = -1;
   o->verbose = 0;
   o->profile_kernels = 0;
