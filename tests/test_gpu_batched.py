@@ -54,11 +54,29 @@ def test_dense_cholesky_converges_like_pcg(golden):
     assert abs(rep["cost"] - pol) <= 1e-6 * pol
 
 
-def test_dense_cholesky_refuses_large_components():
-    sc = scenes.ring_scene(50, 2000, 10)
+def test_whole_gpu_dense_cholesky_matches_oracle(golden):
+    """Camera systems with one large connected component: the blocked whole-GPU Cholesky (potrf / trsm /
+    MFMA update / backward sweep, ba_dense.h).  Step of one linearisation against numpy's dense solve
+    (1e-9 relative), converged cost against the polished minimum of the fixture (1e-6)."""
+    g = golden("ring_50x2000")
+    C, L, d = (int(v) for v in g["ring_params"])
+    sc = scenes.ring_scene(C, L, d)
+    poses, pts, lam = sc["poses_guess"], sc["points_guess"], 1e-3
     with _native.Solver(linear_solver=2) as s:
-        with pytest.raises(ValidationError):
-            s.set_problem(50, 2000, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+        s.set_problem(C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+        out = s.debug_linearization(poses, pts, lam, want_S=False)
+        _, _, rep = s.solve(poses, pts)
+    r, Jc, Jp = lm.linearize(poses, pts, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+    free = np.ones(C, bool)
+    free[0] = False
+    Jc = Jc * free[sc["obs_cam"]][:, None, None]
+    U, V, W, gc, gp, _ = lm.normal_blocks(r, Jc, Jp, sc["obs_cam"], sc["obs_pt"], C, L)
+    S, rhs, Vi = lm.schur_system(U, V, W, gc, gp, sc["obs_cam"], sc["obs_pt"], lam, free)
+    dc = np.linalg.solve(S, -rhs).reshape(C, 6) * free[:, None]
+    np.testing.assert_allclose(out["dc"], dc, rtol=0, atol=1e-9 * np.abs(dc).max())
+    pol = float(g["polished_cost"])
+    assert rep["pcg_iters"] == 0
+    assert abs(rep["cost"] - pol) <= 1e-6 * pol
 
 
 def test_batched_windows_match_individual_solves():

@@ -252,7 +252,7 @@ def test_large_system_path_matches_small_path():
     for small in ("1", "0"):
         os.environ["BA_SMALL_SOLVE"] = small
         try:
-            with _native.Solver(pcg_tol=1e-6) as s:
+            with _native.Solver(pcg_tol=1e-6, linear_solver=1) as s:
                 s.set_problem(C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
                 out.append(s.solve(sc["poses_guess"], sc["points_guess"]))
         finally:

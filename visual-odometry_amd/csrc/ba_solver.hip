@@ -3,6 +3,7 @@
 // Replaces the scipy least_squares call of reference src/bundle_adjustment.py:201-219.
 #include "../../include/ba_amd.h"
 #include "ba_kernels.h"
+#include "ba_dense.h"
 
 #include <algorithm>
 #include <chrono>
@@ -81,6 +82,9 @@ struct ba_handle {
   bool small_solve = false, small_cached = false;
   bool comp_solve = false;  // dense Cholesky per connected component of the camera graph
   size_t comp_lds = 0;
+  bool dense_solve = false;  // whole-GPU dense Cholesky of the reduced system (ba_dense.h)
+  double* dense_A = nullptr;
+  int dense_nt = 0;
   size_t small_lds = 0;
 
   DeviceProblem d{};
@@ -326,6 +330,28 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
     if (h->world > 1) NCCL_TRY(h, h->rccl->Broadcast(d.dc, d.dc, (size_t)6 * d.Cf, ncclDouble, 0, h->comm, h->stream));
     return BA_OK;
   }
+  if (h->dense_solve) {
+    const LmCtrl* ctrl = mode ? d.ctrl : nullptr;
+    const int nt = h->dense_nt;
+    const long ld = (long)nt * DT;
+    double* A = h->dense_A;
+    HIP_TRY(h, hipMemsetAsync(A, 0, (size_t)(nt + 1) * DT * ld * sizeof(double), h->stream));
+    launch_timed(h, KT_PCG, k_dense_assemble, grid_for((long)d.nu * 36 + (long)nt * DT), 256, d, A, ld, nt, lam, o.min_diag, mode);
+    const size_t lds_potrf = (size_t)DPACK * sizeof(double);
+    const size_t lds_trsm = ((size_t)DPACK + DT + 64 * (DT + 1)) * sizeof(double);
+    const size_t lds_back = ((size_t)DPACK + 2 * DT) * sizeof(double);
+    for (int k = 0; k < nt; ++k) {
+      const int R = nt - k;  // tile rows below the diagonal tile (the rhs row included)
+      launch_timed_lds(h, KT_PCG, k_dense_potrf, 1, 256, lds_potrf, A, ld, k, ctrl, d.scal + SC_BADV);
+      launch_timed_lds(h, KT_PCG, k_dense_trsm, 2 * R, 256, lds_trsm, A, ld, k, ctrl);
+      launch_timed(h, KT_PCG, k_dense_update, R * (R + 1) / 2, 256, A, ld, k, nt, ctrl);
+    }
+    for (int k = nt - 1; k >= 0; --k)
+      launch_timed_lds(h, KT_PCG, k_dense_backsolve, k + 1, 256, lds_back, A, ld, k, nt, ctrl, d.dc, 6 * d.Cf);
+    *pcg_iters = -1;
+    if (h->world > 1) NCCL_TRY(h, h->rccl->Broadcast(d.dc, d.dc, (size_t)6 * d.Cf, ncclDouble, 0, h->comm, h->stream));
+    return BA_OK;
+  }
   if (h->small_solve) {
     launch_timed(h, KT_OTHER, k_block_precond, grid_for(d.Cf, 64), 64, d, lam, o.min_diag);
     if (d.nu <= SMALL_THREADS)
@@ -447,7 +473,7 @@ int lm_solve(ba_handle* h, ba_report* rep) {
   HIP_TRY(h, hipMemcpyAsync(d.pts_buf[0], h->pts_init, pts_bytes, hipMemcpyDeviceToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(d.pts_buf[1], h->pts_init, pts_bytes, hipMemcpyDeviceToDevice, h->stream));
 
-  const int check_every = (h->small_solve || h->comp_solve) ? std::max(1, o.lm_check_every) : 1;
+  const int check_every = (h->small_solve || h->comp_solve || h->dense_solve) ? std::max(1, o.lm_check_every) : 1;
   const size_t head_bytes = sizeof(LmHead);
   int enq = 0, rc;
   bool done = false;
@@ -981,12 +1007,22 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
     const int n = 6 * max_cams;
     h->comp_lds = ((size_t)n * (n + 1) + n) * sizeof(double);
     const int want = h->opt.linear_solver;
-    // AUTO: several components (batched windows) -> Cholesky; one small component keeps the PCG path unless asked
-    h->comp_solve = Cf > 0 && max_cams <= COMP_MAX_CAMS && env_int("BA_COMP_SOLVE", 1) &&
-                    (want == BA_SOLVER_DENSE_CHOLESKY || (want == BA_SOLVER_AUTO && n_comp > 1));
-    if (want == BA_SOLVER_DENSE_CHOLESKY && !h->comp_solve)
-      return fail(h, BA_ERR_INVALID, "dense Cholesky needs connected camera groups of at most %d free cameras (largest here: %d)",
-                  COMP_MAX_CAMS, max_cams);
+    // AUTO: several small components (batched windows) -> Cholesky per component; one small system -> the
+    // one-workgroup PCG; up to DENSE_MAX_CAMS cameras -> whole-GPU dense Cholesky; beyond -> multi-kernel PCG.
+    // DENSE_CHOLESKY: per component when they are small, else whole-GPU.  PCG: never a direct solver.
+    constexpr int DENSE_MAX_CAMS = 2048;
+    const bool comps_small = Cf > 0 && max_cams <= COMP_MAX_CAMS && env_int("BA_COMP_SOLVE", 1);
+    h->comp_solve = comps_small && (want == BA_SOLVER_DENSE_CHOLESKY || (want == BA_SOLVER_AUTO && n_comp > 1));
+    if (want == BA_SOLVER_PCG || h->comp_solve) h->dense_solve = false;
+    else if (want == BA_SOLVER_DENSE_CHOLESKY) h->dense_solve = true;
+    else h->dense_solve = !h->small_solve && env_int("BA_DENSE_SOLVE", 1);
+    if (h->dense_solve && Cf > DENSE_MAX_CAMS) {
+      if (want == BA_SOLVER_DENSE_CHOLESKY)
+        return fail(h, BA_ERR_INVALID, "dense Cholesky is limited to %d free cameras (here: %d)", DENSE_MAX_CAMS, Cf);
+      h->dense_solve = false;
+    }
+    if (h->comp_solve || h->dense_solve) h->small_solve = false;
+    h->dense_nt = (6 * Cf + DT - 1) / DT;
     if (h->comp_solve && h->comp_lds > 32 * 1024)
       HIP_TRY(h, hipFuncSetAttribute((const void*)k_solve_components, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)h->comp_lds));
@@ -1036,6 +1072,17 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
       (rc = dev_alloc(h, &h->poses_init, (size_t)7 * C)) || (rc = dev_alloc(h, &d.pts_buf[0], (size_t)3 * L)) ||
       (rc = dev_alloc(h, &d.pts_buf[1], (size_t)3 * L)) || (rc = dev_alloc(h, &h->pts_init, (size_t)3 * L)))
     return rc;
+  h->dense_A = nullptr;
+  if (h->dense_solve) {
+    const size_t ld = (size_t)h->dense_nt * DT;
+    if ((rc = dev_alloc(h, &h->dense_A, (size_t)(h->dense_nt + 1) * DT * ld))) return rc;
+    HIP_TRY(h, hipFuncSetAttribute((const void*)k_dense_potrf, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(DPACK * sizeof(double))));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)k_dense_trsm, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)((DPACK + DT + 64 * (DT + 1)) * sizeof(double))));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)k_dense_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)((DPACK + 2 * DT) * sizeof(double))));
+  }
   d.scal = d.Ugc_slab + (size_t)nslab_u * 27 * C;
   d.S_slab = d.scal + (size_t)SC_COUNT * SCAL_SLABS;
   HIP_TRY(h, hipMemset(d.ctrl, 0, sizeof(LmCtrl)));
@@ -1238,7 +1285,7 @@ int ba_debug_linearization(ba_handle* h, const double* poses, const double* poin
   }
   if (S) {
     if ((rc = fetch(t, d.S, (size_t)36 * d.nu))) return rc;
-    if (h->small_solve || h->comp_solve) {  // these solvers apply the damping on the fly; add it for the export
+    if (h->small_solve || h->comp_solve || h->dense_solve) {  // these solvers apply the damping on the fly; add it for the export
       std::vector<double> ugc, ud((size_t)6 * Cf);
       if ((rc = fetch(ugc, d.Ugc, (size_t)27 * C))) return rc;
       for (int f = 0; f < Cf; ++f)
