@@ -9,8 +9,8 @@
 // right-looking backward sweep turns it into x.
 //
 // Right-looking blocked algorithm, tile 128, three launches per block column k:
-//   k_dense_potrf   one workgroup: Cholesky of the 128 x 128 diagonal tile in LDS (packed lower)
-//   k_dense_trsm    one workgroup per 64 rows below: X = T L_kk^-T (4 lanes per row, L_kk in LDS)
+//   k_dense_potrf   one workgroup: Cholesky of the 128 x 128 diagonal tile, rows in registers
+//   k_dense_trsm    one workgroup per 128 rows below: X = T L_kk^-T (2 lanes per row, rows in registers)
 //   k_dense_update  one workgroup per trailing 128 x 128 tile: C -= P_i P_j^T with
 //                   v_mfma_f64_16x16x4_f64 (each wave a 64 x 64 quadrant = 4 x 4 MFMA tiles, panel
 //                   chunks of 32 columns staged through LDS)                      <- the flops: (6C)^3 / 3
@@ -24,6 +24,33 @@ constexpr int DPACK = DT * (DT + 1) / 2;
 constexpr int DCHUNK = 32, DSTRIDE = 36;  // LDS panel chunk: 128 rows x 32 columns, row stride 36 doubles
 
 typedef double dvec4 __attribute__((ext_vector_type(4)));
+
+// Lower triangle of a 128 x 128 tile <-> packed LDS copy, as flat batched loops (a row-by-row loop
+// waits for one global round trip per row).
+__device__ __forceinline__ void tile_to_packed(const double* __restrict__ At, long ld, double* Lp) {
+  const int t = threadIdx.x;
+#pragma unroll 1
+  for (int e0 = 0; e0 < DT * DT; e0 += 256 * 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 256 * u + t, i = e >> 7, j = e & (DT - 1);
+      v[u] = (j <= i) ? At[(long)i * ld + j] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 256 * u + t, i = e >> 7, j = e & (DT - 1);
+      if (j <= i) Lp[i * (i + 1) / 2 + j] = v[u];
+    }
+  }
+}
+__device__ __forceinline__ void packed_to_tile(const double* Lp, double* __restrict__ At, long ld) {
+  const int t = threadIdx.x;
+  for (int e = t; e < DT * DT; e += 256) {
+    const int i = e >> 7, j = e & (DT - 1);
+    if (j <= i) At[(long)i * ld + j] = Lp[i * (i + 1) / 2 + j];
+  }
+}
 
 __device__ __forceinline__ bool dense_skip(const LmCtrl* ctrl) { return ctrl != nullptr && ctrl->done != 0; }
 
@@ -54,74 +81,109 @@ __global__ __launch_bounds__(256) void k_dense_assemble(DeviceProblem d, double*
   }
 }
 
-// Cholesky of diagonal tile k, in place (lower).  One workgroup, L packed in LDS.
-__global__ __launch_bounds__(256) void k_dense_potrf(double* __restrict__ A, long ld, int k, const LmCtrl* ctrl,
-                                                     double* __restrict__ bad_flag) {
-  extern __shared__ double Lp[];  // [DPACK]
-  if (dense_skip(ctrl)) return;
-  const int t = threadIdx.x;
-  double* At = A + ((long)k * DT) * ld + (long)k * DT;
-  for (int i = 0; i < DT; ++i)
-    for (int j = t; j <= i; j += 256) Lp[i * (i + 1) / 2 + j] = At[(long)i * ld + j];
-  __syncthreads();
-  const int ti = t >> 4, tj = t & 15;
-  bool bad = false;
+// Cholesky of diagonal tile k, in place (lower).  One workgroup; thread (i, h) keeps columns
+// [64 h, 64 h + 64) of row i in REGISTERS (the column loop is fully unrolled, so every index is
+// static): per column one broadcast of the scaled column through LDS and 2 barriers, no LDS
+// read-modify-write chains (those cost ~200 cycles per element and made this kernel 10x slower).
+template <int H>
+__device__ __forceinline__ void potrf_half(double* __restrict__ Arow, int i, double* rc, double* pivinv, bool& bad) {
+  double row[64];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) row[j] = Arow[j];
+#pragma unroll
   for (int c = 0; c < DT; ++c) {
-    double piv = Lp[c * (c + 1) / 2 + c];
-    if (!(piv > 0.0)) { bad = true; piv = 1.0; }
-    const double inv = 1.0 / sqrt(piv);
-    __syncthreads();
-    if (t < DT - c) {
-      const int i = c + t;
-      Lp[i * (i + 1) / 2 + c] *= inv;  // i == c: sqrt(piv)
+    constexpr int dummy = 0; (void)dummy;
+    const int hc = c >> 6, cl = c & 63;
+    if (H == hc && i == c) {
+      double piv = row[cl];
+      if (!(piv > 0.0)) { bad = true; piv = 1.0; }
+      const double dd = sqrt(piv);
+      row[cl] = dd;
+      *pivinv = 1.0 / dd;
     }
     __syncthreads();
-    for (int i = c + 1 + ti; i < DT; i += 16) {
-      const double lic = Lp[i * (i + 1) / 2 + c];
-      for (int j = c + 1 + tj; j <= i; j += 16) Lp[i * (i + 1) / 2 + j] -= lic * Lp[j * (j + 1) / 2 + c];
+    if (H == hc && i > c) {
+      row[cl] *= *pivinv;
+      rc[i] = row[cl];
     }
     __syncthreads();
+    if ((H == 1 || c < 63) && i > c) {
+      const double lic = rc[i];
+#pragma unroll
+      for (int jl = 0; jl < 64; ++jl)
+        if (64 * H + jl > c) row[jl] -= lic * rc[64 * H + jl];  // compile-time test: H and c are constants here
+    }
   }
-  for (int i = 0; i < DT; ++i)
-    for (int j = t; j <= i; j += 256) At[(long)i * ld + j] = Lp[i * (i + 1) / 2 + j];
-  if (bad && t == 0) atomic_add_f64(bad_flag, 1.0);
+#pragma unroll
+  for (int j = 0; j < 64; ++j)
+    if (64 * H + j <= i) Arow[j] = row[j];
 }
 
-// Rows below the diagonal tile: X = T L_kk^-T.  One workgroup per 64 rows, 4 lanes per row.
+__global__ __launch_bounds__(256) void k_dense_potrf(double* __restrict__ A, long ld, int k, const LmCtrl* ctrl,
+                                                     double* __restrict__ bad_flag) {
+  __shared__ double rc[DT];  // column c of L (scaled), rows > c
+  __shared__ double pivinv;
+  if (dense_skip(ctrl)) return;
+  const int t = threadIdx.x, i = t & (DT - 1), h = t >> 7;
+  double* Arow = A + ((long)k * DT + i) * ld + (long)k * DT + 64 * h;
+  bool bad = false;
+  // the two halves run different straight-line code with the same number of barriers (waves 0-1 / 2-3)
+  if (h == 0) potrf_half<0>(Arow, i, rc, &pivinv, bad);
+  else potrf_half<1>(Arow, i, rc, &pivinv, bad);
+  if (bad) atomic_add_f64(bad_flag, 1.0);
+}
+
+// Rows below the diagonal tile: X = T L_kk^-T.  One workgroup per 128 rows; the two lanes (row, p) of a
+// pair keep the entries of parity p of the row in registers, L_kk sits in LDS de-interleaved by column
+// parity; x_j = (t_j - sum_{u<j} x_u L[j][u]) / L[j][j] with the sum split over the pair and combined by
+// one DPP move.  The j loop is fully unrolled: static register indices, no barrier inside.
 __global__ __launch_bounds__(256) void k_dense_trsm(double* __restrict__ A, long ld, int k, const LmCtrl* ctrl) {
   extern __shared__ double sm[];
-  double* Lp = sm;             // [DPACK]
-  double* invd = Lp + DPACK;   // [DT]
-  double* X = invd + DT;       // [64][DT + 1]
+  double* Lde = sm;                 // [DT][2][64]: L[j][2 u2 + p] at (j * 2 + p) * 64 + u2
+  double* invd = Lde + DT * DT;     // [DT]
   if (dense_skip(ctrl)) return;
   const int t = threadIdx.x;
   const double* At = A + ((long)k * DT) * ld + (long)k * DT;
-  for (int i = 0; i < DT; ++i)
-    for (int j = t; j <= i; j += 256) Lp[i * (i + 1) / 2 + j] = At[(long)i * ld + j];
-  const long row0 = (long)(k + 1) * DT + (long)blockIdx.x * 64;
-  double* T = A + row0 * ld + (long)k * DT;
-  for (int e = t; e < 64 * DT; e += 256) {
-    const int r = e >> 7, c = e & (DT - 1);
-    X[r * (DT + 1) + c] = T[(long)r * ld + c];
+#pragma unroll 1
+  for (int e0 = 0; e0 < DT * DT; e0 += 256 * 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 256 * u + t, j = e >> 7, c = e & (DT - 1);
+      v[u] = (c <= j) ? At[(long)j * ld + c] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 256 * u + t, j = e >> 7, c = e & (DT - 1);
+      Lde[(j * 2 + (c & 1)) * 64 + (c >> 1)] = v[u];
+      if (c == j) invd[j] = 1.0 / v[u];
+    }
   }
+  const int row = t >> 1, p = t & 1;
+  double* Trow = A + ((long)(k + 1) * DT + (long)blockIdx.x * DT + row) * ld + (long)k * DT;
+  double x[64];
+#pragma unroll
+  for (int u2 = 0; u2 < 64; ++u2) x[u2] = Trow[2 * u2 + p];
   __syncthreads();
-  if (t < DT) invd[t] = 1.0 / Lp[t * (t + 1) / 2 + t];
-  __syncthreads();
-  const int row = t >> 2, part = t & 3;
-  double* xr = X + row * (DT + 1);
+#pragma unroll
   for (int j = 0; j < DT; ++j) {
-    const double* lj = Lp + j * (j + 1) / 2;
-    double s = 0.0;
-    for (int u = part; u < j; u += 4) s += xr[u] * lj[u];
-    s += dpp_move_f64<0xB1>(s);  // the 4 lanes of a row are one quad
-    s += dpp_move_f64<0x4E>(s);
-    if (part == 0) xr[j] = (xr[j] - s) * invd[j];
-    __syncthreads();
+    const double* lj = Lde + (j * 2 + p) * 64;
+    double s0 = 0.0, s1 = 0.0;
+    // own-parity u = 2 u2 + p < j
+#pragma unroll
+    for (int u2 = 0; u2 < 64; ++u2) {
+      if (2 * u2 + 1 < j) {  // both parities are below j: no lane test needed
+        if (u2 & 1) s1 += x[u2] * lj[u2]; else s0 += x[u2] * lj[u2];
+      } else if (2 * u2 < j) {  // only the even entry is below j
+        if (p == 0) s0 += x[u2] * lj[u2];
+      }
+    }
+    double s = s0 + s1;
+    s += dpp_move_f64<0xB1>(s);  // partner lane of the pair
+    if (p == (j & 1)) x[j >> 1] = (x[j >> 1] - s) * invd[j];
   }
-  for (int e = t; e < 64 * DT; e += 256) {
-    const int r = e >> 7, c = e & (DT - 1);
-    T[(long)r * ld + c] = X[r * (DT + 1) + c];
-  }
+#pragma unroll
+  for (int u2 = 0; u2 < 64; ++u2) Trow[2 * u2 + p] = x[u2];
 }
 
 // Trailing update after block column k: C(ti, tj) -= P_ti P_tj^T for k < tj <= ti (tile row nt, the
@@ -172,10 +234,11 @@ __global__ __launch_bounds__(256) void k_dense_update(double* __restrict__ A, lo
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a].x, fb[b].x, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a].y, fb[b].y, acc[a][b], 0, 0, 0);
-        }
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a].x, fb[b].x, acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a].y, fb[b].y, acc[a][b], 0, 0, 0);
     }
   }
   // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
@@ -203,8 +266,7 @@ __global__ __launch_bounds__(256) void k_dense_backsolve(double* __restrict__ A,
   const int t = threadIdx.x, j = blockIdx.x;
   const double* At = A + ((long)k * DT) * ld + (long)k * DT;
   double* yrow = A + ((long)nt * DT) * ld;
-  for (int i = 0; i < DT; ++i)
-    for (int c = t; c <= i; c += 256) Lp[i * (i + 1) / 2 + c] = At[(long)i * ld + c];
+  tile_to_packed(At, ld, Lp);
   if (t < DT) y[t] = yrow[(long)k * DT + t];
   __syncthreads();
   for (int m = DT - 1; m >= 0; --m) {

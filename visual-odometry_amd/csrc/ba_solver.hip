@@ -337,13 +337,12 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
     double* A = h->dense_A;
     HIP_TRY(h, hipMemsetAsync(A, 0, (size_t)(nt + 1) * DT * ld * sizeof(double), h->stream));
     launch_timed(h, KT_PCG, k_dense_assemble, grid_for((long)d.nu * 36 + (long)nt * DT), 256, d, A, ld, nt, lam, o.min_diag, mode);
-    const size_t lds_potrf = (size_t)DPACK * sizeof(double);
-    const size_t lds_trsm = ((size_t)DPACK + DT + 64 * (DT + 1)) * sizeof(double);
+    const size_t lds_trsm = ((size_t)DT * DT + DT) * sizeof(double);
     const size_t lds_back = ((size_t)DPACK + 2 * DT) * sizeof(double);
     for (int k = 0; k < nt; ++k) {
       const int R = nt - k;  // tile rows below the diagonal tile (the rhs row included)
-      launch_timed_lds(h, KT_PCG, k_dense_potrf, 1, 256, lds_potrf, A, ld, k, ctrl, d.scal + SC_BADV);
-      launch_timed_lds(h, KT_PCG, k_dense_trsm, 2 * R, 256, lds_trsm, A, ld, k, ctrl);
+      launch_timed(h, KT_PCG, k_dense_potrf, 1, 256, A, ld, k, ctrl, d.scal + SC_BADV);
+      launch_timed_lds(h, KT_PCG, k_dense_trsm, R, 256, lds_trsm, A, ld, k, ctrl);
       launch_timed(h, KT_PCG, k_dense_update, R * (R + 1) / 2, 256, A, ld, k, nt, ctrl);
     }
     for (int k = nt - 1; k >= 0; --k)
@@ -1076,10 +1075,8 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
   if (h->dense_solve) {
     const size_t ld = (size_t)h->dense_nt * DT;
     if ((rc = dev_alloc(h, &h->dense_A, (size_t)(h->dense_nt + 1) * DT * ld))) return rc;
-    HIP_TRY(h, hipFuncSetAttribute((const void*)k_dense_potrf, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)(DPACK * sizeof(double))));
     HIP_TRY(h, hipFuncSetAttribute((const void*)k_dense_trsm, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)((DPACK + DT + 64 * (DT + 1)) * sizeof(double))));
+                                   (int)((DT * DT + DT) * sizeof(double))));
     HIP_TRY(h, hipFuncSetAttribute((const void*)k_dense_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)((DPACK + 2 * DT) * sizeof(double))));
   }
