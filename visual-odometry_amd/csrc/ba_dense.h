@@ -187,8 +187,8 @@ __global__ __launch_bounds__(256) void k_dense_trsm(double* __restrict__ A, long
 }
 
 // Trailing update after block column k: C(ti, tj) -= P_ti P_tj^T for k < tj <= ti (tile row nt, the
-// rhs row, takes part with tj < nt).  256 threads, wave (wr, wc) owns a 64 x 64 quadrant.
-__global__ __launch_bounds__(256) void k_dense_update(double* __restrict__ A, long ld, int k, int nt, const LmCtrl* ctrl) {
+// rhs row, takes part with tj < nt).  512 threads = 8 waves of 64 x 32 outputs each.
+__global__ __launch_bounds__(512, 2) void k_dense_update(double* __restrict__ A, long ld, int k, int nt, const LmCtrl* ctrl) {
   __shared__ __align__(16) double sA[DT * DSTRIDE];
   __shared__ __align__(16) double sB[DT * DSTRIDE];
   if (dense_skip(ctrl)) return;
@@ -200,58 +200,73 @@ __global__ __launch_bounds__(256) void k_dense_update(double* __restrict__ A, lo
   const int c = bid - r * (r + 1) / 2;
   const int ti = k + 1 + r, tj = k + 1 + c;
   if (tj >= nt) return;  // the corner below the rhs row is never used
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+  // 8 waves: wave (wr, wc) owns rows [64 wr, +64) x columns [32 wc, +32) = 4 x 2 MFMA tiles (64 accumulator
+  // registers: everything stays in VGPRs, two waves per SIMD)
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 2, wc = w & 3;
   const double* Pi = A + ((long)ti * DT) * ld + (long)k * DT;
   const double* Pj = A + ((long)tj * DT) * ld + (long)k * DT;
-  dvec4 acc[4][4];
+  dvec4 acc[4][2];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = dvec4{0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < 2; ++b) acc[a][b] = dvec4{0.0, 0.0, 0.0, 0.0};
   const int l15 = lane & 15, l4 = lane >> 4;
+  // software pipeline: the loads of chunk kc + 1 are in flight while chunk kc is multiplied
+  double2 va[4], vb[4];
+  auto fetch = [&](int kc) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = t + 512 * it, row = idx >> 4, c2 = (idx & 15) * 2;
+      va[it] = *reinterpret_cast<const double2*>(Pi + (long)row * ld + kc + c2);
+      vb[it] = *reinterpret_cast<const double2*>(Pj + (long)row * ld + kc + c2);
+    }
+  };
+  fetch(0);
   for (int kc = 0; kc < DT; kc += DCHUNK) {
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int idx = t + 256 * it, row = idx >> 4, c2 = (idx & 15) * 2;
-      const double2 va = *reinterpret_cast<const double2*>(Pi + (long)row * ld + kc + c2);
-      const double2 vb = *reinterpret_cast<const double2*>(Pj + (long)row * ld + kc + c2);
-      *reinterpret_cast<double2*>(&sA[row * DSTRIDE + c2]) = va;
-      *reinterpret_cast<double2*>(&sB[row * DSTRIDE + c2]) = vb;
+    for (int it = 0; it < 4; ++it) {
+      const int idx = t + 512 * it, row = idx >> 4, c2 = (idx & 15) * 2;
+      *reinterpret_cast<double2*>(&sA[row * DSTRIDE + c2]) = va[it];
+      *reinterpret_cast<double2*>(&sB[row * DSTRIDE + c2]) = vb[it];
     }
     __syncthreads();
+    if (kc + DCHUNK < DT) fetch(kc + DCHUNK);
 #pragma unroll
     for (int ks = 0; ks < DCHUNK; ks += 8) {
-      double2 fa[4], fb[4];
+      double2 fa[4], fb[2];
       // lane supplies k = ks + 2 * (lane >> 4) + {0, 1}: two MFMA k-groups (the order of the k sum is free
       // as long as A and B use the same assignment)
 #pragma unroll
       for (int a = 0; a < 4; ++a)
         fa[a] = *reinterpret_cast<const double2*>(&sA[(wr * 64 + 16 * a + l15) * DSTRIDE + ks + 2 * l4]);
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
-        fb[b] = *reinterpret_cast<const double2*>(&sB[(wc * 64 + 16 * b + l15) * DSTRIDE + ks + 2 * l4]);
+      for (int b = 0; b < 2; ++b)
+        fb[b] = *reinterpret_cast<const double2*>(&sB[(wc * 32 + 16 * b + l15) * DSTRIDE + ks + 2 * l4]);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a].x, fb[b].x, acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a].x, fb[b].x, acc[a][b], 0, 0, 0);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a].y, fb[b].y, acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a].y, fb[b].y, acc[a][b], 0, 0, 0);
     }
   }
   // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
-  double* Ct = A + ((long)ti * DT + wr * 64) * ld + (long)tj * DT + wc * 64;
+  double* Ct = A + ((long)ti * DT + wr * 64) * ld + (long)tj * DT + wc * 32;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < 4; ++a) {  // 8 loads in flight, then 8 stores
+    double cv[2][4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        double* p = Ct + (long)(16 * a + l4 + 4 * q) * ld + 16 * b + l15;
-        *p -= acc[a][b][q];
-      }
+      for (int q = 0; q < 4; ++q) cv[b][q] = Ct[(long)(16 * a + l4 + 4 * q) * ld + 16 * b + l15];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Ct[(long)(16 * a + l4 + 4 * q) * ld + 16 * b + l15] = cv[b][q] - acc[a][b][q];
+  }
 }
 
 // Backward sweep, step k (descending): x_k = L_kk^-T y_k (every workgroup, redundantly), then

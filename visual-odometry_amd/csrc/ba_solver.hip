@@ -343,7 +343,7 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
       const int R = nt - k;  // tile rows below the diagonal tile (the rhs row included)
       launch_timed(h, KT_PCG, k_dense_potrf, 1, 256, A, ld, k, ctrl, d.scal + SC_BADV);
       launch_timed_lds(h, KT_PCG, k_dense_trsm, R, 256, lds_trsm, A, ld, k, ctrl);
-      launch_timed(h, KT_PCG, k_dense_update, R * (R + 1) / 2, 256, A, ld, k, nt, ctrl);
+      launch_timed(h, KT_PCG, k_dense_update, R * (R + 1) / 2, 512, A, ld, k, nt, ctrl);
     }
     for (int k = nt - 1; k >= 0; --k)
       launch_timed_lds(h, KT_PCG, k_dense_backsolve, k + 1, 256, lds_back, A, ld, k, nt, ctrl, d.dc, 6 * d.Cf);
