@@ -327,7 +327,6 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
   if (h->comp_solve) {
     launch_timed_lds(h, KT_PCG, k_solve_components, d.n_comp, 64, h->comp_lds, d, lam, o.min_diag);
     *pcg_iters = -1;
-    if (h->world > 1) NCCL_TRY(h, h->rccl->Broadcast(d.dc, d.dc, (size_t)6 * d.Cf, ncclDouble, 0, h->comm, h->stream));
     return BA_OK;
   }
   if (h->dense_solve) {
@@ -348,7 +347,6 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
     for (int k = nt - 1; k >= 0; --k)
       launch_timed_lds(h, KT_PCG, k_dense_backsolve, k + 1, 256, lds_back, A, ld, k, nt, ctrl, d.dc, 6 * d.Cf);
     *pcg_iters = -1;
-    if (h->world > 1) NCCL_TRY(h, h->rccl->Broadcast(d.dc, d.dc, (size_t)6 * d.Cf, ncclDouble, 0, h->comm, h->stream));
     return BA_OK;
   }
   if (h->small_solve) {
@@ -358,9 +356,8 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
     else
       launch_timed_lds(h, KT_PCG, k_solve_small<2>, 1, SMALL_THREADS, h->small_lds, d, lam, o.min_diag, tol2, o.pcg_max_iter);
     *pcg_iters = -1;  // lives in scal[SC_PCGIT]
-    // every rank solved the same system; ship rank 0's step so that all replicas of the poses stay
-    // bit-identical (LDS atomics make the summation order, hence the last bits, rank-dependent)
-    if (h->world > 1) NCCL_TRY(h, h->rccl->Broadcast(d.dc, d.dc, (size_t)6 * d.Cf, ncclDouble, 0, h->comm, h->stream));
+    // every rank solved the same all-reduced system with a solver whose summation order is fixed (no
+    // atomics): the camera step is bit-identical on all ranks and needs no broadcast
     return BA_OK;
   }
   k_damp_mirror<<<grid_for(d.nu), 256, 0, h->stream>>>(d, lam, o.min_diag);
