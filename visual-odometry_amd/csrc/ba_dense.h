@@ -12,10 +12,11 @@
 //   k_dense_potrf   one workgroup: Cholesky of the 128 x 128 diagonal tile, rows in registers
 //   k_dense_trsm    one workgroup per 128 rows below: X = T L_kk^-T (2 lanes per row, rows in registers)
 //   k_dense_update  one workgroup per trailing 128 x 128 tile: C -= P_i P_j^T with
-//                   v_mfma_f64_16x16x4_f64 (each wave a 64 x 64 quadrant = 4 x 4 MFMA tiles, panel
-//                   chunks of 32 columns staged through LDS)                      <- the flops: (6C)^3 / 3
-// then nt launches of k_dense_backsolve.  Bound: fp64 MFMA (78.6 TFLOP/s) for k_dense_update; the
-// potrf / trsm pair is a latency chain of nt steps.
+//                   v_mfma_f64_16x16x4_f64 (8 waves of 64 x 32 outputs = 4 x 2 MFMA tiles each, panel
+//                   chunks of 32 columns software-pipelined through LDS)          <- the flops: (6C)^3 / 3
+// then nt launches of k_dense_backsolve.  Bound: fp64 MFMA issue for k_dense_update (measured on MI355X:
+// one v_mfma_f64_16x16x4_f64 per 58.6 ns per wave, 33-44 TFLOP/s chip-wide, tools/mfma_f64_bench.hip);
+// the potrf / trsm pair is a latency chain of nt steps.
 #pragma once
 #include "ba_kernels.h"
 
