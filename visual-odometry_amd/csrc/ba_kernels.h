@@ -1446,21 +1446,30 @@ __global__ void k_copy_tail(const double* __restrict__ src, double* __restrict__
 
 // ------------------------------------------------------------------------------------------------
 // k_fold_scalars (multi-GPU only): fold the privatised scalar copies into out[0, SC_NSUM) (sum; max
-// for the two inf-norm slots) so that one small all-reduce can combine the ranks.  Slots whose value
-// is replicated (camera part) are zeroed on every rank but the root, so that the sum over ranks is
-// the root's value.  out[SC_COUNT] receives the point-gradient inf-norm for the MAX all-reduce.
-__global__ __launch_bounds__(64) void k_fold_scalars(DeviceProblem d, double* __restrict__ out, int is_root) {
+// for the two inf-norm slots) so that ONE small sum all-reduce can combine the ranks.  Slots whose
+// value is replicated (camera part) are zeroed on every rank but the root, so that the sum over ranks
+// is the root's value.  The point-gradient inf-norm needs a max over ranks: rank r puts its value in
+// out[SC_COUNT + r] and zeros in the other ranks' slots; after the sum every rank holds all of them.
+constexpr int FOLD_MAX_RANKS = 64;
+__global__ __launch_bounds__(128) void k_fold_scalars(DeviceProblem d, double* __restrict__ out, int rank, int world) {
   const int i = threadIdx.x;
-  if (i >= SC_NSUM) return;
-  const bool is_max = (i == SC_GINF || i == SC_GINF_C);
-  double v = 0.0;
-  for (int k = 0; k < SCAL_SLABS; ++k) {
-    const double x = d.scal[(size_t)k * SC_COUNT + i];
-    v = is_max ? fmax(v, x) : v + x;
+  if (i >= SC_COUNT) {
+    if (i - SC_COUNT < world) out[i] = 0.0;
+    if (i - SC_COUNT != rank) return;
   }
-  const bool replicated = (i == SC_GDOT_C || i == SC_DHD_C || i == SC_DNORM2_C || i == SC_XNORM2_C || i == SC_GINF_C);
-  if (replicated && !is_root) v = 0.0;
-  if (i == SC_GINF) { out[SC_COUNT] = v; v = 0.0; }
+  const int slot = i >= SC_COUNT ? SC_GINF : i;
+  double v = 0.0;
+  if (slot < SC_NSUM) {
+    const bool is_max = (slot == SC_GINF || slot == SC_GINF_C);
+    for (int k = 0; k < SCAL_SLABS; ++k) {
+      const double x = d.scal[(size_t)k * SC_COUNT + slot];
+      v = is_max ? fmax(v, x) : v + x;
+    }
+    const bool replicated = (slot == SC_GDOT_C || slot == SC_DHD_C || slot == SC_DNORM2_C || slot == SC_XNORM2_C ||
+                             slot == SC_GINF_C);
+    if (replicated && rank != 0) v = 0.0;
+    if (i == SC_GINF) v = 0.0;  // travels in the per-rank slots
+  }
   out[i] = v;
 }
 
@@ -1469,7 +1478,7 @@ __global__ __launch_bounds__(64) void k_fold_scalars(DeviceProblem d, double* __
 // Folds the privatised scalar copies (or takes the rank-combined values from `folded`), then does
 // exactly what the host used to do after a read-back: gain ratio, accept / reject, Nielsen's lambda
 // update, scipy-style termination tests (scipy/optimize/_lsq/common.py:705-717 vocabulary).
-__global__ __launch_bounds__(256) void k_lm_decide(DeviceProblem d, const double* __restrict__ folded) {
+__global__ __launch_bounds__(256) void k_lm_decide(DeviceProblem d, const double* __restrict__ folded, int world) {
   LmCtrl* c = d.ctrl;
   if (c->done) return;
   __shared__ double part[8][SC_COUNT];
@@ -1491,7 +1500,9 @@ __global__ __launch_bounds__(256) void k_lm_decide(DeviceProblem d, const double
   if (t < SC_NSUM) {
     double v;
     if (folded) {
-      v = (t == SC_GINF) ? folded[SC_COUNT] : folded[t];
+      v = folded[t];
+      if (t == SC_GINF)
+        for (int r = 0; r < world; ++r) v = fmax(v, folded[SC_COUNT + r]);
     } else {
       const bool is_max = (t == SC_GINF || t == SC_GINF_C);
       v = part[0][t];

@@ -484,16 +484,14 @@ int lm_solve(ba_handle* h, ba_report* rep) {
       if ((rc = do_reduced_solve(h, -1.0, &pcg_it))) return rc;
       enqueue_trial(h, -1.0, nullptr, nullptr, nullptr, nullptr);
       if (h->world > 1) {
-        // fold on the device, combine the ranks (sum; max for the point-gradient norm)
-        k_fold_scalars<<<1, 64, 0, h->stream>>>(d, h->scal_fold, h->rank == 0);
-        NCCL_TRY(h, h->rccl->GroupStart());
-        NCCL_TRY(h, h->rccl->AllReduce(h->scal_fold, h->scal_fold, SC_NSUM, ncclDouble, ncclSum, h->comm, h->stream));
-        NCCL_TRY(h, h->rccl->AllReduce(h->scal_fold + SC_COUNT, h->scal_fold + SC_COUNT, 1, ncclDouble, ncclMax,
+        // fold on the device, combine the ranks with one sum all-reduce (the max of the point-gradient norm
+        // travels in per-rank slots)
+        k_fold_scalars<<<1, 128, 0, h->stream>>>(d, h->scal_fold, h->rank, h->world);
+        NCCL_TRY(h, h->rccl->AllReduce(h->scal_fold, h->scal_fold, (size_t)SC_COUNT + h->world, ncclDouble, ncclSum,
                                        h->comm, h->stream));
-        NCCL_TRY(h, h->rccl->GroupEnd());
-        launch_timed(h, KT_OTHER, k_lm_decide, 1, 256, d, (const double*)h->scal_fold);
+        launch_timed(h, KT_OTHER, k_lm_decide, 1, 256, d, (const double*)h->scal_fold, h->world);
       } else {
-        launch_timed(h, KT_OTHER, k_lm_decide, 1, 256, d, (const double*)nullptr);
+        launch_timed(h, KT_OTHER, k_lm_decide, 1, 256, d, (const double*)nullptr, 1);
       }
     }
     HIP_TRY(h, hipMemcpyAsync(&c, d.ctrl, head_bytes, hipMemcpyDeviceToHost, h->stream));
@@ -630,7 +628,8 @@ int ba_comm_unique_id(char* id128) {
 
 int ba_comm_init(ba_handle* h, int32_t rank, int32_t world, const char* id128) {
   if (!h) return BA_ERR_INVALID;
-  if (world < 1 || rank < 0 || rank >= world || !id128) return fail(h, BA_ERR_INVALID, "bad rank/world/id");
+  if (world < 1 || world > FOLD_MAX_RANKS || rank < 0 || rank >= world || !id128)
+    return fail(h, BA_ERR_INVALID, "bad rank/world/id (at most %d ranks)", FOLD_MAX_RANKS);
   if (h->comm) return fail(h, BA_ERR_STATE, "communicator already initialised");
   h->rccl = rccl_load();
   if (!h->rccl) return fail(h, BA_ERR_DEVICE, "librccl.so could not be loaded: %s", dlerror());
@@ -1056,7 +1055,7 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
   if ((rc = dev_alloc(h, &d.W, (size_t)18 * n)) || (rc = dev_alloc(h, &d.V, (size_t)6 * L)) ||
       (rc = dev_alloc(h, &d.gp, (size_t)3 * L)) || (rc = dev_alloc(h, &d.Ugc_part, (size_t)27 * C)) ||
       (rc = dev_alloc(h, &d.S, (size_t)36 * (nu + gap_blocks + nl))) ||
-      (rc = dev_alloc(h, &h->scal_fold, (size_t)SC_COUNT + 8)) ||
+      (rc = dev_alloc(h, &h->scal_fold, (size_t)SC_COUNT + FOLD_MAX_RANKS)) ||
       (rc = dev_alloc(h, &d.Ugc_slab, (size_t)nslab_u * 27 * C + (size_t)SC_COUNT * SCAL_SLABS +
                                           (size_t)nslab_s * d.s_slab_stride)) ||
       (rc = dev_alloc(h, &d.ctrl, 1)) ||
