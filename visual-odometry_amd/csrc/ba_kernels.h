@@ -51,6 +51,12 @@ struct LmCtrl : LmHead {
   int pcg_hist[LM_HISTORY], acc_hist[LM_HISTORY];
 };
 static_assert(sizeof(LmHead) % 8 == 0, "LmHead must not have tail padding");
+// Copy of the head in pinned host memory: k_lm_decide stores it there and then raises `seq`, the host
+// spins on `seq` instead of paying a copy + stream synchronisation per LM iteration.
+struct LmMirror {
+  LmHead head;
+  int seq, pad;
+};
 
 struct DeviceProblem {
   int C, Cf, L, L_obs, n;  // cameras, free cameras, landmarks, landmarks with >= 1 observation, observations
@@ -735,14 +741,17 @@ __global__ __launch_bounds__(64, 1) void k_schur_staged(DeviceProblem d, double 
 // list (lanes 0..41 = the 42 entries of a row, 8 rows in flight per wave), the four partial sums are
 // combined in a fixed order.  Reads every contribution row once: 336 B per (pair, run, block of
 // k_schur_staged).
-__global__ __launch_bounds__(256) void k_gather_S(DeviceProblem d, int solver_mode) {
+__global__ __launch_bounds__(256) void k_gather_S(DeviceProblem d, int solver_mode, double lam, double min_diag,
+                                                  int precond) {
   __shared__ double part[4][64];
+  __shared__ double sblk[36];
   __shared__ double upart[8][32];
   __shared__ double ugc[32];
   int from_slabs = 1;  // U / gc were accumulated by a k_linearize since the last gather
   if (solver_mode) {
     if (d.ctrl->done) return;
     from_slabs = d.ctrl->need_lin;
+    lam = d.ctrl->lam;
   }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const bool extra = (int)blockIdx.x >= d.nu;  // blocks past nu: U / gc of the fixed cameras (exported, never solved for)
@@ -805,8 +814,24 @@ __global__ __launch_bounds__(256) void k_gather_S(DeviceProblem d, int solver_mo
       sum += ugc[i <= c ? sym6_index(i, c) : sym6_index(c, i)];
     }
     d.S[(long)s * 36 + lane] = sum;
+    if (diag && precond) sblk[lane] = sum;
   } else {
     d.rhs[6L * f + lane - 36] = sum + ugc[21 + lane - 36];
+  }
+  // single GPU: the block-Jacobi preconditioner of this camera, Minv = (S_ff + lam max(diag U_f, min_diag))^-1,
+  // right here (k_block_precond's job; with several GPUs S is only final after the all-reduce)
+  if (diag && precond) {
+    __builtin_amdgcn_wave_barrier();  // wave 0 only: LDS keeps one wave's accesses in order
+    if (lane == 0) {
+      double A[36];
+#pragma unroll
+      for (int i = 0; i < 36; ++i) A[i] = sblk[i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) A[7 * i] += lam * fmax(ugc[sym6_index(i, i)], min_diag);
+      if (!spd_inverse6(A)) atomic_add_f64(&SCAL_MINE(d)[SC_BADV], 1.0);
+#pragma unroll
+      for (int i = 0; i < 36; ++i) d.Minv[(long)f * 36 + i] = A[i];
+    }
   }
 }
 
@@ -1478,9 +1503,20 @@ __global__ __launch_bounds__(128) void k_fold_scalars(DeviceProblem d, double* _
 // Folds the privatised scalar copies (or takes the rank-combined values from `folded`), then does
 // exactly what the host used to do after a read-back: gain ratio, accept / reject, Nielsen's lambda
 // update, scipy-style termination tests (scipy/optimize/_lsq/common.py:705-717 vocabulary).
-__global__ __launch_bounds__(256) void k_lm_decide(DeviceProblem d, const double* __restrict__ folded, int world) {
+__device__ __forceinline__ void lm_publish(LmMirror* mirror, const LmHead& h, int seq) {
+  if (!mirror) return;
+  mirror->head = h;
+  __threadfence_system();
+  __hip_atomic_store(&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(256) void k_lm_decide(DeviceProblem d, const double* __restrict__ folded, int world,
+                                                   LmMirror* mirror, int seq) {
   LmCtrl* c = d.ctrl;
-  if (c->done) return;
+  if (c->done) {  // launched after termination: only tell the host that this launch is through
+    if (threadIdx.x == 0) lm_publish(mirror, *static_cast<const LmHead*>(c), seq);
+    return;
+  }
   __shared__ double part[8][SC_COUNT];
   __shared__ double s[SC_COUNT];
   const int t = threadIdx.x, i = t & (SC_COUNT - 1), g = t / SC_COUNT;  // 8 groups x 32 slots
@@ -1575,4 +1611,5 @@ __global__ __launch_bounds__(256) void k_lm_decide(DeviceProblem d, const double
     if (stop || it >= h.max_iters) h.done = 1;  // status stays 0 (max_iters) unless a test fired
   }
   *static_cast<LmHead*>(c) = h;
+  lm_publish(mirror, h, seq);
 }

@@ -101,6 +101,8 @@ struct ba_handle {
   struct Span { int cls; hipEvent_t a, b; int iter; };
   int span_iter = 0;
   LmCtrl* ctrl_host = nullptr;  // pinned
+  LmMirror* mirror = nullptr;   // pinned, written by k_lm_decide
+  LmMirror* mirror_dev = nullptr;
   std::vector<Span> spans;
   double ktime_ms[BA_KERNEL_CLASSES] = {0, 0, 0, 0, 0, 0};
   int kcount[BA_KERNEL_CLASSES] = {0, 0, 0, 0, 0, 0};
@@ -318,7 +320,10 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
   const ba_options& o = h->opt;
   const int mode = lam < 0.0;
   launch_schur(h, lam);
-  if (h->schur_cpb > 0) launch_timed(h, KT_OTHER, k_gather_S, d.nu + (d.C - d.Cf), 256, d, mode);
+  // the gather also inverts the damped diagonal blocks when they are final there (one GPU, one-workgroup PCG)
+  const int fused_precond = h->schur_cpb > 0 && h->world == 1 && h->small_solve;
+  if (h->schur_cpb > 0)
+    launch_timed(h, KT_OTHER, k_gather_S, d.nu + (d.C - d.Cf), 256, d, mode, lam, o.min_diag, fused_precond);
   else launch_timed(h, KT_OTHER, k_reduce_S, grid_for(d.s_slab_stride + 27L * d.C), 256, d, mode);
   const size_t red_count = (size_t)d.nu * 36 + (size_t)6 * d.Cf + (size_t)27 * d.C;
   if (h->world > 1)  // the one exchange step of the path: partial S, reduced rhs, U / gc summed over the shards
@@ -350,7 +355,7 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
     return BA_OK;
   }
   if (h->small_solve) {
-    launch_timed(h, KT_OTHER, k_block_precond, grid_for(d.Cf, 64), 64, d, lam, o.min_diag);
+    if (!fused_precond) launch_timed(h, KT_OTHER, k_block_precond, grid_for(d.Cf, 64), 64, d, lam, o.min_diag);
     if (d.nu <= SMALL_THREADS)
       launch_timed_lds(h, KT_PCG, k_solve_small<1>, 1, SMALL_THREADS, h->small_lds, d, lam, o.min_diag, tol2, o.pcg_max_iter);
     else
@@ -470,7 +475,7 @@ int lm_solve(ba_handle* h, ba_report* rep) {
   HIP_TRY(h, hipMemcpyAsync(d.pts_buf[1], h->pts_init, pts_bytes, hipMemcpyDeviceToDevice, h->stream));
 
   const int check_every = (h->small_solve || h->comp_solve || h->dense_solve) ? std::max(1, o.lm_check_every) : 1;
-  const size_t head_bytes = sizeof(LmHead);
+  h->mirror->seq = 0;
   int enq = 0, rc;
   bool done = false;
   while (!done && enq < o.max_iters) {
@@ -489,14 +494,23 @@ int lm_solve(ba_handle* h, ba_report* rep) {
         k_fold_scalars<<<1, 128, 0, h->stream>>>(d, h->scal_fold, h->rank, h->world);
         NCCL_TRY(h, h->rccl->AllReduce(h->scal_fold, h->scal_fold, (size_t)SC_COUNT + h->world, ncclDouble, ncclSum,
                                        h->comm, h->stream));
-        launch_timed(h, KT_OTHER, k_lm_decide, 1, 256, d, (const double*)h->scal_fold, h->world);
+        launch_timed(h, KT_OTHER, k_lm_decide, 1, 256, d, (const double*)h->scal_fold, h->world, h->mirror_dev, enq + 1);
       } else {
-        launch_timed(h, KT_OTHER, k_lm_decide, 1, 256, d, (const double*)nullptr, 1);
+        launch_timed(h, KT_OTHER, k_lm_decide, 1, 256, d, (const double*)nullptr, 1, h->mirror_dev, enq + 1);
       }
     }
-    HIP_TRY(h, hipMemcpyAsync(&c, d.ctrl, head_bytes, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    done = c.done != 0;
+    // k_lm_decide stores the control head into pinned host memory and then raises seq: spin on it (a copy +
+    // stream synchronisation costs ~20 us of idle GPU per iteration); long iterations fall back to a blocking wait
+    const auto spin_until = clk::now() + std::chrono::milliseconds(2);
+    while (__atomic_load_n(&h->mirror->seq, __ATOMIC_ACQUIRE) != enq) {
+      if (clk::now() > spin_until) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (__atomic_load_n(&h->mirror->seq, __ATOMIC_ACQUIRE) != enq)
+          return fail(h, BA_ERR_DEVICE, "the LM control block did not reach the host");
+        break;
+      }
+    }
+    done = h->mirror->head.done != 0;
   }
   HIP_TRY(h, hipMemcpyAsync(&c, d.ctrl, sizeof c, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -583,7 +597,9 @@ int ba_create(const ba_options* opt, ba_handle** out) {
   h->device = dev;
   if (hipSetDevice(dev) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess ||
       hipHostMalloc((void**)&h->scal_host, SCAL_BYTES) != hipSuccess ||
-      hipHostMalloc((void**)&h->ctrl_host, sizeof(LmCtrl)) != hipSuccess) {
+      hipHostMalloc((void**)&h->ctrl_host, sizeof(LmCtrl)) != hipSuccess ||
+      hipHostMalloc((void**)&h->mirror, sizeof(LmMirror), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&h->mirror_dev, h->mirror, 0) != hipSuccess) {
     delete h;
     return BA_ERR_DEVICE;
   }
@@ -598,6 +614,7 @@ void ba_destroy(ba_handle* h) {
   if (h->comm && h->rccl) (void)h->rccl->CommDestroy(h->comm);
   if (h->scal_host) (void)hipHostFree(h->scal_host);
   if (h->ctrl_host) (void)hipHostFree(h->ctrl_host);
+  if (h->mirror) (void)hipHostFree(h->mirror);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
