@@ -93,7 +93,6 @@ __device__ __forceinline__ void potrf_half(double* __restrict__ Arow, int i, dou
   for (int j = 0; j < 64; ++j) row[j] = Arow[j];
 #pragma unroll
   for (int c = 0; c < DT; ++c) {
-    constexpr int dummy = 0; (void)dummy;
     const int hc = c >> 6, cl = c & 63;
     if (H == hc && i == c) {
       double piv = row[cl];

@@ -215,17 +215,11 @@ __global__ __launch_bounds__(64, LIN_WAVES) void k_linearize(DeviceProblem d, co
 #pragma unroll
           for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
         }
-#ifndef DBG_NO_WSTORE
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
           for (int c = 0; c < 3; ++c) d.W[(long)(3 * i + c) * n + k] = Jc[i] * Jp[c] + Jc[6 + i] * Jp[3 + c];
-#endif
-#ifdef DBG_NO_UACC
-        if (false) {
-#else
         if (is_free) {
-#endif
           cur_cam = cam;
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
@@ -1122,25 +1116,13 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
   double gamma = 0.0, gamma0 = 0.0, delta_ = 0.0, inv_gamma_old = 1.0, denom_old = 1.0;
   static_assert(SMALL_THREADS == 512, "the partial sums below are written out for 8 waves");
   int it = 0;
-#ifdef DBG_SMALL_TIMING
-  long long dbgT[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
   while (true) {
-#ifdef DBG_SMALL_TIMING
-    const long long t0 = clock64();
-#endif
     // (A) every stored block: B z_j and B^T z_i into its slot
 #pragma unroll
     for (int k = 0; k < NB; ++k)
       if (ij[k] >= 0)
         small_block_products(B[k], ij[k] >> 16, ij[k] & 0xffff, zv, slot + (size_t)(tid + k * SMALL_THREADS) * SMALL_CSTRIDE);
-#ifdef DBG_SMALL_TIMING
-    const long long t1 = clock64();
-#endif
     __syncthreads();
-#ifdef DBG_SMALL_TIMING
-    const long long t2 = clock64();
-#endif
     // (B) w = S z gathered per row; gamma = r.z, delta = z.w in one reduction
     double w[SMALL_VPT], pg = 0.0, pd = 0.0;
 #pragma unroll
@@ -1161,19 +1143,10 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
         pd += w[v] * z[v];
       }
     }
-#ifdef DBG_SMALL_TIMING
-    const long long t3 = clock64();
-#endif
     pg = wave_sum_dpp(pg);
     pd = wave_sum_dpp(pd);
     if (lane == 0) { red[2 * wv] = pg; red[2 * wv + 1] = pd; }
-#ifdef DBG_SMALL_TIMING
-    const long long t4 = clock64();
-#endif
     __syncthreads();
-#ifdef DBG_SMALL_TIMING
-    const long long t5 = clock64();
-#endif
     {
       const double g01 = red[0] + red[2], g23 = red[4] + red[6], g45 = red[8] + red[10], g67 = red[12] + red[14];
       const double d01 = red[1] + red[3], d23 = red[5] + red[7], d45 = red[9] + red[11], d67 = red[13] + red[15];
@@ -1181,18 +1154,12 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
       delta_ = (d01 + d23) + (d45 + d67);
     }
     if (it == 0) gamma0 = gamma;
-#ifdef DBG_SMALL_FIXED
-    if (it >= 32) break;
-#else
     if (it >= max_iter || !(gamma > tol2 * gamma0) || !(gamma > 0.0)) break;
-#endif
     // beta = gamma / gamma_old; alpha = gamma / (delta - beta gamma / alpha_old) = gamma / (delta - beta^2 denom_old):
     // one reciprocal on the critical path, 1 / gamma for the next iteration computed beside it
     const double beta = it ? gamma * inv_gamma_old : 0.0;
     const double denom = it ? delta_ - beta * beta * denom_old : delta_;
-#ifndef DBG_SMALL_FIXED
     if (!(denom > 0.0)) break;
-#endif
     const double alpha = gamma * fast_rcp(denom);
     inv_gamma_old = fast_rcp(gamma);
     denom_old = denom;
@@ -1209,21 +1176,8 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
     __builtin_amdgcn_wave_barrier();  // the 6 rows of a camera belong to this wave: LDS keeps a wave's accesses in order
     precondition();
     ++it;
-#ifdef DBG_SMALL_TIMING
-    const long long t7 = clock64();
-#endif
     __syncthreads();
-#ifdef DBG_SMALL_TIMING
-    const long long t8 = clock64();
-    dbgT[0] += t1 - t0; dbgT[1] += t2 - t1; dbgT[2] += t3 - t2; dbgT[3] += t4 - t3; dbgT[4] += t5 - t4;
-    dbgT[5] += t6 - t5; dbgT[6] += t7 - t6; dbgT[7] += t8 - t7;
-#endif
   }
-#ifdef DBG_SMALL_TIMING
-  if (lane == 0 && it > 0)
-    printf("wave %d it %d: products %lld bar %lld | gather %lld wavesum %lld bar %lld | scalars %lld | update+precond %lld bar %lld\n",
-           wv, it, dbgT[0] / it, dbgT[1] / it, dbgT[2] / it, dbgT[3] / it, dbgT[4] / it, dbgT[5] / it, dbgT[6] / it, dbgT[7] / it);
-#endif
 #pragma unroll
   for (int v = 0; v < SMALL_VPT; ++v)
     if (ent[v] >= 0) d.dc[ent[v]] = x[v];

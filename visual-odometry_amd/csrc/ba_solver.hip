@@ -79,7 +79,7 @@ struct ba_handle {
   std::vector<uint8_t> fixed;
   int g_lin = 16, g_schur = 64, lpg_lin = 1, lpg_schur = 1, lpg_back = 1;
   int schur_cpb = 0;  // > 0: k_schur_staged with this many chunks per block
-  bool small_solve = false, small_cached = false;
+  bool small_solve = false;
   bool comp_solve = false;  // dense Cholesky per connected component of the camera graph
   size_t comp_lds = 0;
   bool dense_solve = false;  // whole-GPU dense Cholesky of the reduced system (ba_dense.h)
