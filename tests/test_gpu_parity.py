@@ -304,3 +304,27 @@ def test_config3_passes_the_reference_cost():
     assert abs(cost_eval - rep["cost"]) <= 1e-12 * rep["cost"]
     h = rep["cost_history"]
     assert all(b <= a for a, b in zip(h, h[1:]))
+
+
+def test_unstructured_visibility_matches_oracle():
+    """Every landmark seen by a random camera subset (no two tracks need share a camera signature: the
+    staged Schur kernel then writes a contribution tile at almost every step, and S is dense) against the
+    oracle's LM on the same scene; also the atomics Schur path (BA_SCHUR_STAGED=0) against the staged one."""
+    import os
+    sc = scenes.ring_scene(12, 600, 5, visibility="random")
+    C, L = len(sc["poses_guess"]), len(sc["points_guess"])
+    _, _, o = lm.lm_solve(sc["poses_guess"], sc["points_guess"], sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+    costs = []
+    for staged in ("1", "0"):
+        os.environ["BA_SCHUR_STAGED"] = staged
+        try:
+            with _native.Solver() as s:
+                s.set_problem(C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+                out = s.debug_linearization(sc["poses_guess"], sc["points_guess"], 1e-3, want_S=True)
+                _, _, rep = s.solve(sc["poses_guess"], sc["points_guess"])
+        finally:
+            os.environ.pop("BA_SCHUR_STAGED", None)
+        assert abs(rep["cost"] - o.cost) <= 1e-6 * o.cost, (staged, rep["cost"], o.cost)
+        costs.append((rep["cost"], out["S"], out["rhs"]))
+    np.testing.assert_allclose(costs[0][1], costs[1][1], rtol=0, atol=1e-10 * np.abs(costs[1][1]).max())
+    np.testing.assert_allclose(costs[0][2], costs[1][2], rtol=0, atol=1e-10 * np.abs(costs[1][2]).max())

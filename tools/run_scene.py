@@ -10,10 +10,10 @@ from src import _native
 ap = argparse.ArgumentParser()
 ap.add_argument("--C", type=int, default=1000); ap.add_argument("--L", type=int, default=200000)
 ap.add_argument("--d", type=int, default=5); ap.add_argument("--verbose", type=int, default=1)
-ap.add_argument("--reps", type=int, default=1)
+ap.add_argument("--reps", type=int, default=1); ap.add_argument("--visibility", default="ring")
 ap.add_argument("--opt", nargs="*", default=[])
 a = ap.parse_args()
-t0 = time.time(); sc = scenes.ring_scene(a.C, a.L, a.d); print("scene built in %.1fs" % (time.time() - t0), flush=True)
+t0 = time.time(); sc = scenes.ring_scene(a.C, a.L, a.d, visibility=a.visibility); print("scene built in %.1fs" % (time.time() - t0), flush=True)
 opts = {}
 for kv in a.opt:
     k, v = kv.split("="); opts[k] = float(v) if "." in v or "e" in v else int(v)

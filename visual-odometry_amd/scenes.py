@@ -264,9 +264,23 @@ def ring_observation_index(C: int, L: int, d: int) -> Tuple[np.ndarray, np.ndarr
     return flat_cam[order].astype(np.int32), flat_pt[order].astype(np.int32)
 
 
-def ring_scene(C: int, L: int, d: int, sigma_px: float = 0.5, seed: int = 0, f: float = 500.0) -> Scene:
+def random_observation_index(C: int, L: int, d: int, seed: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Unstructured visibility: landmark j is seen by d cameras drawn at random (no two landmarks need
+    share a camera set); image-major, ascending landmark id inside an image like the ring index."""
+    rng = np.random.default_rng(seed)
+    cams = np.argsort(rng.random((L, C)), axis=1)[:, :d]  # d distinct cameras per landmark
+    flat_cam = cams.reshape(-1)
+    flat_pt = np.repeat(np.arange(L), d)
+    order = np.lexsort((flat_pt, flat_cam))
+    return flat_cam[order].astype(np.int32), flat_pt[order].astype(np.int32)
+
+
+def ring_scene(C: int, L: int, d: int, sigma_px: float = 0.5, seed: int = 0, f: float = 500.0,
+               visibility: str = "ring") -> Scene:
     """SURVEY.md Appendix C ``ring_CxL``: cfg2 = (50, 20000, 10), cfg3 = (1000, 200000, 5),
-    cfg4 = (10000, 2000000, 5).  Fully vectorised (no per-landmark Python loops)."""
+    cfg4 = (10000, 2000000, 5).  Fully vectorised (no per-landmark Python loops).  ``visibility="random"``
+    keeps the geometry but lets every landmark be seen by d random cameras (images then have unequal
+    observation counts: a stress case for the solver, not a reference-compatible scene)."""
     rng = np.random.default_rng(seed)
     intr = np.array([f, f, 320.0, 240.0, 0.0, 0.0, 0.0])
     poses_w = ring_poses(C)
@@ -274,7 +288,8 @@ def ring_scene(C: int, L: int, d: int, sigma_px: float = 0.5, seed: int = 0, f: 
     th = rng.uniform(0, 2 * np.pi, L)
     z = rng.uniform(0, 2, L)
     pts_w = np.stack([r * np.cos(th), r * np.sin(th), z], axis=1)
-    obs_cam, obs_pt = ring_observation_index(C, L, d)
+    obs_cam, obs_pt = (ring_observation_index(C, L, d) if visibility == "ring"
+                       else random_observation_index(C, L, d, seed + 1000))
     R = quat_to_rot(poses_w[:, 3:7])
     dd = pts_w[obs_pt] - poses_w[obs_cam, :3]
     Rc = R[obs_cam]
