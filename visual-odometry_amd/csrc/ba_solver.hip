@@ -960,7 +960,7 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
   {
     const size_t u_bytes = (size_t)C * 27 * sizeof(double);
     const size_t s_bytes = ((size_t)nu * 36 + (size_t)6 * Cf) * sizeof(double);
-    h->d.nslab_u = env_int("BA_NSLAB_U", (int)std::min<size_t>(256, std::max<size_t>(1, ((size_t)8 << 20) / u_bytes)));
+    h->d.nslab_u = env_int("BA_NSLAB_U", (int)std::min<size_t>(32, std::max<size_t>(1, ((size_t)8 << 20) / u_bytes)));
     h->d.nslab_s = env_int("BA_NSLAB_S", (int)std::min<size_t>(16, std::max<size_t>(1, ((size_t)32 << 20) / s_bytes)));
     if (h->schur_cpb > 0) h->d.nslab_s = 0;  // the staged path writes contribution rows instead
     h->d.s_slab_stride = (long)nu * 36 + 6L * Cf;
