@@ -49,6 +49,18 @@ typedef enum { BA_STOP_MAX_ITERS = 0, BA_STOP_GTOL = 1, BA_STOP_FTOL = 2, BA_STO
 
 typedef enum { BA_SOLVER_AUTO = 0, BA_SOLVER_PCG = 1, BA_SOLVER_DENSE_CHOLESKY = 2 } ba_linear_solver;
 
+/* Robust loss, applied to every scalar residual with the semantics of the `loss=` / `f_scale=`
+ * arguments of scipy.optimize.least_squares (scipy/optimize/_lsq/least_squares.py:186-236): the hook
+ * that the reference's call (bundle_adjustment.py:201-212) leaves at its default, 'linear'.
+ * cost = 0.5 * f_scale^2 * sum rho((r / f_scale)^2). */
+typedef enum {
+  BA_LOSS_LINEAR = 0,  /* rho(z) = z                      (the reference's setting) */
+  BA_LOSS_SOFT_L1 = 1, /* rho(z) = 2 (sqrt(1 + z) - 1)    */
+  BA_LOSS_HUBER = 2,   /* rho(z) = z if z <= 1 else 2 sqrt(z) - 1 */
+  BA_LOSS_CAUCHY = 3,  /* rho(z) = ln(1 + z)              */
+  BA_LOSS_ARCTAN = 4   /* rho(z) = arctan(z)              */
+} ba_loss;
+
 /* Solver settings.  The reference hard-codes its settings as literals in the least_squares call
  * (bundle_adjustment.py:201-212: ftol = xtol = gtol = 1e-6, max_nfev = 2000); defaults here are
  * tighter (ftol = scipy's own default) so that the converged cost is at or below the reference's
@@ -72,10 +84,12 @@ typedef struct {
   int32_t device;           /* HIP device ordinal; -1 = current device */
   int32_t verbose;          /* 1 = print one line per LM iteration to stderr */
   int32_t profile_kernels;  /* 1 = bracket every kernel class with HIP events (ba_get_kernel_times) */
+  int32_t loss;             /* ba_loss, default BA_LOSS_LINEAR */
+  double f_scale;           /* soft margin between inlier and outlier residuals, pixels; default 1.0 */
 } ba_options;
 
 typedef struct {
-  double cost0;        /* 0.5 sum r^2 at the initial guess */
+  double cost0;        /* cost at the initial guess: 0.5 sum r^2, or the robust cost when opt.loss is set */
   double cost;         /* at the returned estimate */
   double grad_inf;     /* |J^T r|_inf at the last linearisation */
   double lambda;       /* final damping */
@@ -160,21 +174,23 @@ int ba_solve_batched(ba_handle* h, int32_t n_problems, const int32_t* cam_off, c
  * order ([u0, v0, u1, v1, ...]); residuals may be NULL.  Replaces
  * BundleAdjustment.residual_function (bundle_adjustment.py:20-87).  n_behind (may be NULL) receives
  * the number of observations with z <= 0.  Returns BA_ERR_NUMERICAL if some z == 0, as
- * PinHoleCamera.project raises ProcessingError there (camera.py:129-132). */
+ * PinHoleCamera.project raises ProcessingError there (camera.py:129-132).  The residuals are always the
+ * plain re-projection errors; *cost is the robust cost when opt.loss is set (as scipy's result.cost). */
 int ba_evaluate(ba_handle* h, const double* poses, const double* points, double* residuals, double* cost,
                 int32_t* n_behind);
 
 /* Analytic Jacobian blocks in the caller's observation order: Jc[n_obs*12] = d r / d(dt, dtheta)
  * (2x6 row-major, zero for fixed poses), Jp[n_obs*6] = d r / dP (2x3).  The reference has no analytic
  * Jacobian (scipy differentiates numerically, scipy/optimize/_numdiff.py); exported so tests can check
- * the blocks against finite differences of the reference residual. */
+ * the blocks against finite differences of the reference residual (never scaled by a robust loss). */
 int ba_jacobian_blocks(ba_handle* h, const double* poses, const double* points, double* Jc, double* Jp);
 
 /* Debug export of one linearisation at (poses, points) with damping lambda, in the caller's index
  * order: U[C*36], V[L*9], W[n_obs*18] (6x3 row-major), gc[C*6], gp[L*3], S[(6C)^2] dense row-major with
  * identity rows for fixed cameras, rhs[6C] (the reduced system is S dc = -rhs), and the LM step
- * dc[C*6], dp[L*3] from the configured linear solver.  Any pointer may be NULL.  No reference
- * counterpart (the reference never forms normal equations). */
+ * dc[C*6], dp[L*3] from the configured linear solver.  Any pointer may be NULL.  With a robust loss the
+ * blocks are those of the re-weighted system (rows scaled as scipy's scale_for_robust_loss_function
+ * does).  No reference counterpart (the reference never forms normal equations). */
 int ba_debug_linearization(ba_handle* h, const double* poses, const double* points, double lambda, double* U,
                            double* V, double* W, double* gc, double* gp, double* S, double* rhs, double* dc,
                            double* dp);

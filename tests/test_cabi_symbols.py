@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     # sizeof / offsetof printed by gcc for include/ba_amd.h (x86-64 SysV)
-    assert ctypes.sizeof(_native.BaOptions) == 112
+    assert ctypes.sizeof(_native.BaOptions) == 128 and _native.BaOptions.f_scale.offset == 120
     assert ctypes.sizeof(_native.BaReport) == 3160
     assert _native.BaReport.solve_ms.offset == 64 and _native.BaReport.cost_history.offset == 88
 

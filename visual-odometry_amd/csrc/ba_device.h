@@ -16,6 +16,59 @@ struct Intrinsics {
   int has_dist;
 };
 
+// Robust loss on every scalar residual, with the semantics of scipy.optimize.least_squares' `loss=` /
+// `f_scale=` arguments (scipy/optimize/_lsq/least_squares.py:186-236, the hook the reference's call at
+// bundle_adjustment.py:201-212 leaves at its default 'linear'): cost = 0.5 C^2 sum rho((f / C)^2).
+enum RobustKind { LOSS_LINEAR = 0, LOSS_SOFT_L1 = 1, LOSS_HUBER = 2, LOSS_CAUCHY = 3, LOSS_ARCTAN = 4 };
+struct RobustLoss {
+  int kind;
+  double c2, inv_c2;  // f_scale^2 and its reciprocal
+};
+
+// 0.5 C^2 rho(z), z = f^2 / C^2
+__device__ __forceinline__ double robust_cost(const RobustLoss& l, double f) {
+  const double z = f * f * l.inv_c2;
+  double rho;
+  switch (l.kind) {
+    case LOSS_SOFT_L1: rho = 2.0 * (sqrt(1.0 + z) - 1.0); break;
+    case LOSS_HUBER: rho = z <= 1.0 ? z : 2.0 * sqrt(z) - 1.0; break;
+    case LOSS_CAUCHY: rho = log1p(z); break;
+    case LOSS_ARCTAN: rho = atan(z); break;
+    default: rho = z;
+  }
+  return 0.5 * l.c2 * rho;
+}
+
+// Triggs' correction as scipy applies it (scipy/optimize/_lsq/common.py:scale_for_robust_loss_function):
+// the Jacobian row of f is multiplied by s = sqrt(max(rho' + 2 rho'' z, eps)) and f becomes f rho' / s, so
+// that J^T f is the gradient of the robust cost and J^T J its Gauss-Newton Hessian.  Returns the cost term.
+__device__ __forceinline__ double robust_scale(const RobustLoss& l, double& f, double& s) {
+  const double z = f * f * l.inv_c2;
+  double rho, r1, r2z;  // r2z = rho'' * z
+  switch (l.kind) {
+    case LOSS_SOFT_L1: {
+      const double t = 1.0 + z, it = 1.0 / sqrt(t);
+      rho = 2.0 * (t * it - 1.0); r1 = it; r2z = -0.5 * it / t * z;
+    } break;
+    case LOSS_HUBER:
+      if (z <= 1.0) { rho = z; r1 = 1.0; r2z = 0.0; }
+      else { const double iz = 1.0 / sqrt(z); rho = 2.0 * z * iz - 1.0; r1 = iz; r2z = -0.5 * iz; }
+      break;
+    case LOSS_CAUCHY: {
+      const double it = 1.0 / (1.0 + z);
+      rho = log1p(z); r1 = it; r2z = -it * it * z;
+    } break;
+    case LOSS_ARCTAN: {
+      const double it = 1.0 / (1.0 + z * z);
+      rho = atan(z); r1 = it; r2z = -2.0 * z * it * it * z;
+    } break;
+    default: rho = z; r1 = 1.0; r2z = 0.0;
+  }
+  s = sqrt(fmax(r1 + 2.0 * r2z, 2.220446049250313e-16));
+  f *= r1 / s;
+  return 0.5 * l.c2 * rho;
+}
+
 __device__ __forceinline__ void quat_to_R(const double* __restrict__ q, double R[9]) {
   const double w = q[0], x = q[1], y = q[2], z = q[3];
   R[0] = 1 - 2 * y * y - 2 * z * z; R[1] = 2 * x * y - 2 * w * z;     R[2] = 2 * x * z + 2 * w * y;

@@ -61,6 +61,7 @@ struct LmMirror {
 struct DeviceProblem {
   int C, Cf, L, L_obs, n;  // cameras, free cameras, landmarks, landmarks with >= 1 observation, observations
   Intrinsics K;
+  RobustLoss loss;
   // structure (constant per problem)
   const int* o_cam; const double* o_u; const double* o_v; const int* o_src; const int* o_lm;
   const int* o_free;     // [n]  free-camera index of the observation's image, -1 = fixed pose
@@ -201,7 +202,19 @@ __global__ __launch_bounds__(64, LIN_WAVES) void k_linearize(DeviceProblem d, co
         linearize_obs(d.K, poses + 7 * cam, P, first ? u_first : d.o_u[k], first ? v_first : d.o_v[k], r, Jc, Jp, zc);
         nbehind += (zc <= 0.0);
         nzero += (zc == 0.0);
-        cost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
+        if (d.loss.kind == LOSS_LINEAR) {
+          cost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
+        } else {  // robust loss: scale each residual and its Jacobian row (wave-uniform branch)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            double s;
+            cost += robust_scale(d.loss, r[i], s);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) Jc[6 * i + c] *= s;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Jp[3 * i + c] *= s;
+          }
+        }
         v[0] += Jp[0] * Jp[0] + Jp[3] * Jp[3];
         v[1] += Jp[0] * Jp[1] + Jp[3] * Jp[4];
         v[2] += Jp[0] * Jp[2] + Jp[3] * Jp[5];
@@ -280,7 +293,7 @@ __global__ __launch_bounds__(256) void k_cost(DeviceProblem d,
     reproject(d.K, X, d.o_u[k], d.o_v[k], r0, r1);
     nbehind += (X[2] <= 0.0);
     nzero += (X[2] == 0.0);
-    cost += 0.5 * (r0 * r0 + r1 * r1);
+    cost += d.loss.kind == LOSS_LINEAR ? 0.5 * (r0 * r0 + r1 * r1) : robust_cost(d.loss, r0) + robust_cost(d.loss, r1);
     if (res_out) {
       const long s = d.o_src[k];
       res_out[2 * s] = r0;
@@ -545,16 +558,19 @@ __global__ __launch_bounds__(64, 2) void k_schur(DeviceProblem d, double lam, do
 //      rows that the host's inverted index lists for it: no atomics, no memset, and S is bitwise
 //      reproducible from run to run.
 // Algorithmic bytes are those of k_schur, but W is read from HBM exactly once.
-constexpr int SCH_CAP = 64;     // observations per chunk (= lanes of a wave)
+// Chunk shape: 40 observations / 7-column flush passes keep the kernel at 248 VGPRs and 19 KB of LDS,
+// so two waves share a SIMD (8 blocks per CU); measured against 64 / 14 / one wave per SIMD:
+// 26.3 vs 29.3 us on BASELINE configs[1], 64.6 vs 71.9 us on configs[2].
+constexpr int SCH_CAP = 40;     // observations per chunk (<= lanes of a wave)
 constexpr int SCH_MAXLM = 32;   // landmarks per chunk
 constexpr int SCH_MAXLEN = 10;  // longest track the staged kernel takes (55 pairs <= 64 lanes)
 constexpr int SCH_MAXCPB = 32;  // chunks per block
 constexpr int SYW_STRIDE = 38;  // Y[18] | W[18] | 2 pad doubles (rows stay 16-byte aligned)
 constexpr int CTR_ROW = 42;     // doubles per contribution row: 6x6 block | 6 reduced-rhs entries
-constexpr int FLUSH_NV = 14, FLUSH_STRIDE = 15;
+constexpr int FLUSH_NV = 7, FLUSH_STRIDE = FLUSH_NV;  // columns per flush pass (divides CTR_ROW; odd: no LDS padding needed)
 
 template <int G>
-__global__ __launch_bounds__(64, 1) void k_schur_staged(DeviceProblem d, double lam, double min_diag, int cpb) {
+__global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double lam, double min_diag, int cpb) {
   __shared__ double stage[64 * FLUSH_STRIDE];
   __shared__ __align__(16) double sYW[SCH_CAP * SYW_STRIDE];
   __shared__ double sVi[SCH_MAXLM * 9];  // Vd^-1 (6) | gp (3) per landmark of the chunk

@@ -578,6 +578,8 @@ void ba_default_options(ba_options* o) {
   o->device = -1;
   o->verbose = 0;
   o->profile_kernels = 0;
+  o->loss = BA_LOSS_LINEAR;
+  o->f_scale = 1.0;
 }
 
 int ba_create(const ba_options* opt, ba_handle** out) {
@@ -586,6 +588,11 @@ int ba_create(const ba_options* opt, ba_handle** out) {
   ba_handle* h = new (std::nothrow) ba_handle();
   if (!h) return BA_ERR_NOMEM;
   if (opt) h->opt = *opt; else ba_default_options(&h->opt);
+  if (h->opt.loss < BA_LOSS_LINEAR || h->opt.loss > BA_LOSS_ARCTAN || !(h->opt.f_scale > 0.0) ||
+      !std::isfinite(h->opt.f_scale)) {
+    delete h;
+    return BA_ERR_INVALID;  // scipy raises ValueError for an unknown loss or f_scale <= 0 as well
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
     delete h;
@@ -888,7 +895,7 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
       sch_lm.push_back(L_obs);
       sch_k.push_back(lm_ptr[L_obs]);
       const int n_chunks = (int)sch_lm.size() - 1;
-      const int want_blocks = 256 * env_int("BA_SCHUR_BLOCKS_PER_CU", 4);
+      const int want_blocks = 256 * env_int("BA_SCHUR_BLOCKS_PER_CU", 8);
       const int cpb = std::min(SCH_MAXCPB, env_int("BA_CPB", std::max(1, (n_chunks + want_blocks - 1) / want_blocks)));
       const int n_blocks = (n_chunks + cpb - 1) / cpb;
       sch_flush.assign(n_chunks, 0u);
@@ -1049,6 +1056,7 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
   d.C = C; d.Cf = Cf; d.L = L; d.L_obs = L_obs; d.n = n;
   d.K = Intrinsics{intr[0], intr[1], intr[2], intr[3], intr[4], intr[5], intr[6],
                    (intr[4] != 0.0 || intr[5] != 0.0 || intr[6] != 0.0) ? 1 : 0};
+  d.loss = RobustLoss{h->opt.loss, h->opt.f_scale * h->opt.f_scale, 1.0 / (h->opt.f_scale * h->opt.f_scale)};
   d.nu = nu; d.nl = nl; d.nb = nb;
   int rc;
   if ((rc = dev_upload(h, &d.o_cam, o_cam)) || (rc = dev_upload(h, &d.o_u, o_u)) || (rc = dev_upload(h, &d.o_v, o_v)) ||

@@ -17,6 +17,8 @@ _LIB_PATH = os.environ.get("BA_AMD_LIB") or os.path.join(
     os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib", "libba_amd.so")
 
 STATUS_NAMES = {0: "max_iters", 1: "gtol", 2: "ftol", 3: "xtol"}
+# scipy.optimize.least_squares' names for its `loss=` argument -> ba_loss (include/ba_amd.h)
+LOSSES = {"linear": 0, "soft_l1": 1, "huber": 2, "cauchy": 3, "arctan": 4}
 
 
 class BaOptions(C.Structure):
@@ -26,7 +28,7 @@ class BaOptions(C.Structure):
         ("min_diag", C.c_double), ("accept_ratio", C.c_double), ("guard_cheirality", C.c_int32),
         ("linear_solver", C.c_int32), ("pcg_tol", C.c_double), ("pcg_max_iter", C.c_int32),
         ("pcg_check_every", C.c_int32), ("lm_check_every", C.c_int32), ("device", C.c_int32), ("verbose", C.c_int32),
-        ("profile_kernels", C.c_int32),
+        ("profile_kernels", C.c_int32), ("loss", C.c_int32), ("f_scale", C.c_double),
     ]
 
 
@@ -132,6 +134,10 @@ class Solver:
         for k, v in options.items():
             if not hasattr(self.opt, k):
                 raise ValidationError(f"unknown solver option {k!r}")
+            if k == "loss" and isinstance(v, str):
+                if v not in LOSSES:
+                    raise ValidationError(f"`loss` must be one of {sorted(LOSSES)}, got {v!r}")
+                v = LOSSES[v]
             setattr(self.opt, k, v)
         self._h = _P()
         rc = lib.ba_create(C.byref(self.opt), C.byref(self._h))
