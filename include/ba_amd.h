@@ -52,7 +52,9 @@ typedef enum { BA_SOLVER_AUTO = 0, BA_SOLVER_PCG = 1, BA_SOLVER_DENSE_CHOLESKY =
 /* Robust loss, applied to every scalar residual with the semantics of the `loss=` / `f_scale=`
  * arguments of scipy.optimize.least_squares (scipy/optimize/_lsq/least_squares.py:186-236): the hook
  * that the reference's call (bundle_adjustment.py:201-212) leaves at its default, 'linear'.
- * cost = 0.5 * f_scale^2 * sum rho((r / f_scale)^2). */
+ * cost = 0.5 * f_scale^2 * sum rho((r / f_scale)^2).  The objective is scipy's; the linearisation weights
+ * each residual row by sqrt(rho') (iteratively re-weighted least squares) instead of scipy's clamped
+ * second-order correction, which stalls LM on outlier-dominated initial guesses. */
 typedef enum {
   BA_LOSS_LINEAR = 0,  /* rho(z) = z                      (the reference's setting) */
   BA_LOSS_SOFT_L1 = 1, /* rho(z) = 2 (sqrt(1 + z) - 1)    */
@@ -189,8 +191,7 @@ int ba_jacobian_blocks(ba_handle* h, const double* poses, const double* points, 
  * order: U[C*36], V[L*9], W[n_obs*18] (6x3 row-major), gc[C*6], gp[L*3], S[(6C)^2] dense row-major with
  * identity rows for fixed cameras, rhs[6C] (the reduced system is S dc = -rhs), and the LM step
  * dc[C*6], dp[L*3] from the configured linear solver.  Any pointer may be NULL.  With a robust loss the
- * blocks are those of the re-weighted system (rows scaled as scipy's scale_for_robust_loss_function
- * does).  No reference counterpart (the reference never forms normal equations). */
+ * blocks are those of the re-weighted system (residuals and Jacobian rows times sqrt(rho')).  No reference counterpart (the reference never forms normal equations). */
 int ba_debug_linearization(ba_handle* h, const double* poses, const double* points, double lambda, double* U,
                            double* V, double* W, double* gc, double* gp, double* S, double* rhs, double* dc,
                            double* dp);

@@ -58,22 +58,33 @@ def retract(poses: np.ndarray, dc: np.ndarray, free: np.ndarray) -> np.ndarray:
 
 # ----------------------------------------------------------------------------- linearisation
 def linearize(poses, points, obs_cam, obs_pt, obs_uv, intr, want_jac=True):
-    """r (n,2), Jc = d r/d[dt, dtheta] (n,2,6), Jp = d r/dP (n,2,3).  k1=k2=k3=0 only."""
+    """r (n,2), Jc = d r/d[dt, dtheta] (n,2,6), Jp = d r/dP (n,2,3); radial distortion as the
+    reference's PinHoleCamera.project applies it (src/camera.py:141-159)."""
     fx, fy, cx, cy = intr[:4]
+    k1, k2, k3 = (intr[4], intr[5], intr[6]) if len(intr) >= 7 else (0.0, 0.0, 0.0)
     R = quat_to_rot(poses[:, 3:7])[obs_cam]
     d = points[obs_pt] - poses[obs_cam, :3]
     xc = np.einsum("nji,nj->ni", R, d)  # R^T d
     x, y, z = xc[:, 0], xc[:, 1], xc[:, 2]
     iz = 1.0 / z
-    r = np.stack([obs_uv[:, 0] - (fx * x * iz + cx), obs_uv[:, 1] - (fy * y * iz + cy)], axis=1)
+    xn, yn = x * iz, y * iz
+    r2 = xn * xn + yn * yn
+    f = 1.0 + k1 * r2 + k2 * r2**2 + k3 * r2**3
+    r = np.stack([obs_uv[:, 0] - (fx * xn * f + cx), obs_uv[:, 1] - (fy * yn * f + cy)], axis=1)
     if not want_jac:
         return r, int(np.sum(z <= 0)), None
     n = len(x)
+    fp = k1 + 2 * k2 * r2 + 3 * k3 * r2**2  # d f / d r2
+    # d pixel / d (xn, yn), then d (xn, yn) / d Xc = [iz 0 -xn iz; 0 iz -yn iz]
+    a00, a01 = fx * (f + 2 * xn * xn * fp), fx * (2 * xn * yn * fp)
+    a10, a11 = fy * (2 * xn * yn * fp), fy * (f + 2 * yn * yn * fp)
     Jpi = np.zeros((n, 2, 3))
-    Jpi[:, 0, 0] = fx * iz
-    Jpi[:, 0, 2] = -fx * x * iz * iz
-    Jpi[:, 1, 1] = fy * iz
-    Jpi[:, 1, 2] = -fy * y * iz * iz
+    Jpi[:, 0, 0] = a00 * iz
+    Jpi[:, 0, 1] = a01 * iz
+    Jpi[:, 0, 2] = -(a00 * xn + a01 * yn) * iz
+    Jpi[:, 1, 0] = a10 * iz
+    Jpi[:, 1, 1] = a11 * iz
+    Jpi[:, 1, 2] = -(a10 * xn + a11 * yn) * iz
     RT = np.transpose(R, (0, 2, 1))
     A = np.einsum("nij,njk->nik", Jpi, RT)  # Jpi R^T
     skew = np.zeros((n, 3, 3))
@@ -82,6 +93,45 @@ def linearize(poses, points, obs_cam, obs_pt, obs_uv, intr, want_jac=True):
     skew[:, 2, 0] = -y; skew[:, 2, 1] = x
     Jc = np.concatenate([A, -np.einsum("nij,njk->nik", Jpi, skew)], axis=2)
     return r, Jc, -A
+
+
+def rho_functions(loss: str, z: np.ndarray):
+    """(rho, rho', rho'') of scipy's implemented losses (scipy/optimize/_lsq/least_squares.py:186-236)."""
+    if loss == "linear":
+        return z, np.ones_like(z), np.zeros_like(z)
+    if loss == "soft_l1":
+        t = 1 + z
+        return 2 * (np.sqrt(t) - 1), t**-0.5, -0.5 * t**-1.5
+    if loss == "huber":
+        big = z > 1
+        zs = np.where(big, z, 1.0)
+        return (np.where(big, 2 * np.sqrt(zs) - 1, z), np.where(big, zs**-0.5, 1.0),
+                np.where(big, -0.5 * zs**-1.5, 0.0))
+    if loss == "cauchy":
+        return np.log1p(z), 1 / (1 + z), -1 / (1 + z) ** 2
+    if loss == "arctan":
+        t = 1 + z * z
+        return np.arctan(z), 1 / t, -2 * z / t**2
+    raise ValueError(loss)
+
+
+def robustify(r, Jc, Jp, loss: str, f_scale: float):
+    """Re-weighting for a robust loss on every scalar residual f (z = (f / C)^2): the Jacobian row and f
+    are both multiplied by sqrt(rho'(z)), so that J^T f is the gradient of the robust cost
+    0.5 C^2 sum rho(z) -- the objective of scipy's `loss=` -- and J^T J = J^T rho' J majorises its
+    Hessian (all implemented rho are concave in z).  scipy itself uses Triggs' second-order term,
+    s^2 = max(rho' + 2 rho'' z, eps) (scale_for_robust_loss_function, scipy/optimize/_lsq/common.py);
+    clamped like that the rows of outliers vanish from J^T J, the Marquardt diagonal with them, and LM
+    rejects every step from a poor initial guess, so the solver (HIP and this restatement) keeps the
+    first-order weight only.  Same objective and minimisers, different Gauss-Newton model.
+    Returns the scaled (r, Jc, Jp) and the robust cost."""
+    z = (r / f_scale) ** 2
+    rho0, rho1, _ = rho_functions(loss, z)
+    cost = 0.5 * f_scale**2 * float(np.sum(rho0))
+    if loss == "linear":
+        return r, Jc, Jp, cost
+    s = np.sqrt(rho1)
+    return r * s, (None if Jc is None else Jc * s[:, :, None]), (None if Jp is None else Jp * s[:, :, None]), cost
 
 
 def normal_blocks(r, Jc, Jp, obs_cam, obs_pt, C, L):
@@ -218,6 +268,8 @@ class LMOptions:
     linear_solver: str = "direct"  # "direct" | "pcg"
     pcg_tol: float = 1e-2
     pcg_max_iter: int = 500
+    loss: str = "linear"  # scipy's names: linear | soft_l1 | huber | cauchy | arctan
+    f_scale: float = 1.0
 
 
 @dataclass
@@ -248,7 +300,8 @@ def lm_solve(poses, points, obs_cam, obs_pt, obs_uv, intr, free: Optional[np.nda
     lam, nu = opt.lambda0, 2.0
     r, Jc, Jp = linearize(poses, points, obs_cam, obs_pt, obs_uv, intr)
     Jc = Jc * free[obs_cam][:, None, None]
-    U, V, W, gc, gp, cost = normal_blocks(r, Jc, Jp, obs_cam, obs_pt, C, L)
+    r, Jc, Jp, cost = robustify(r, Jc, Jp, opt.loss, opt.f_scale)
+    U, V, W, gc, gp, _ = normal_blocks(r, Jc, Jp, obs_cam, obs_pt, C, L)
     rep.cost0 = cost
     rep.costs.append(cost)
     _, nbehind, _ = linearize(poses, points, obs_cam, obs_pt, obs_uv, intr, want_jac=False)
@@ -282,7 +335,7 @@ def lm_solve(poses, points, obs_cam, obs_pt, obs_uv, intr, free: Optional[np.nda
         poses_t = retract(poses, dc, free)
         points_t = points + dp
         rt, nbehind_t, _ = linearize(poses_t, points_t, obs_cam, obs_pt, obs_uv, intr, want_jac=False)
-        cost_t = 0.5 * float(np.sum(rt * rt))
+        cost_t = robustify(rt, None, None, opt.loss, opt.f_scale)[3]
         rho = (cost - cost_t) / pred if pred > 0 else -1.0
         if opt.guard_cheirality and nbehind_t > nbehind:
             rho = -1.0
@@ -304,7 +357,8 @@ def lm_solve(poses, points, obs_cam, obs_pt, obs_uv, intr, free: Optional[np.nda
                 break
             r, Jc, Jp = linearize(poses, points, obs_cam, obs_pt, obs_uv, intr)
             Jc = Jc * free[obs_cam][:, None, None]
-            U, V, W, gc, gp, cost = normal_blocks(r, Jc, Jp, obs_cam, obs_pt, C, L)
+            r, Jc, Jp, _ = robustify(r, Jc, Jp, opt.loss, opt.f_scale)
+            U, V, W, gc, gp, _ = normal_blocks(r, Jc, Jp, obs_cam, obs_pt, C, L)
         else:
             lam = min(opt.lambda_max, lam * nu)
             nu *= 2.0

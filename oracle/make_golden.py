@@ -106,9 +106,11 @@ def seeded_scene(spec, n_lm, lm_std, pos_std, rot_std):
     return cam, feats, poses_cf0, lms_cf0, guesses, lm_guess
 
 
-def noisy_scene(P, L):
+def noisy_scene(P, L, dist=(0.0, 0.0, 0.0), outlier_fraction=0.0):
+    """`dist` = (k1, k2, k3) of the reference camera model; `outlier_fraction` of the pixels get a gross
+    error of 20-60 px (drawn after everything else, so the inlier part equals the plain scene's)."""
     rng = np.random.default_rng(0)
-    cam = PinHoleCamera(fx=1000.0, fy=1000.0, cx=320.0, cy=240.0)
+    cam = PinHoleCamera(fx=1000.0, fy=1000.0, cx=320.0, cy=240.0, k1=dist[0], k2=dist[1], k3=dist[2])
     landmarks = LandmarkGenerator((2.8, 3.2), (-0.5, 0.5), (-0.5, 0.5)).generate_random(num_landmarks=L, seed=0)
     quat_cam = G.quaternion_from_euler_angles(np.array([-np.pi / 2, 0.0, -np.pi / 2]))
     poses = []
@@ -120,6 +122,14 @@ def noisy_scene(P, L):
     poses_cf0, lms_cf0 = to_cf0(poses, landmarks)
     guesses, lm_guess = perturb(poses_cf0, lms_cf0, lambda *s: rng.standard_normal(s if len(s) > 1 else s[0]),
                                 0.1, 0.05, 0.02)
+    if outlier_fraction > 0:
+        for f in feats:
+            n = len(f.features_2d.points_2d)
+            bad = rng.choice(n, int(round(outlier_fraction * n)), replace=False)
+            shift = rng.uniform(20.0, 60.0, (len(bad), 2)) * rng.choice([-1.0, 1.0], (len(bad), 2))
+            pts2 = f.features_2d.points_2d.copy()
+            pts2[bad] += shift
+            f.features_2d.points_2d = pts2
     return cam, feats, poses_cf0, lms_cf0, guesses, lm_guess
 
 
@@ -201,6 +211,36 @@ def run_reference(scene, pk, shipped: bool):
     return out, res
 
 
+ROBUST_LOSSES = ("soft_l1", "huber", "cauchy", "arctan")
+
+
+def run_robust(scene, pk):
+    """scipy's robust-loss hook (loss=, f_scale=) driven by THE REFERENCE's residual_function with the
+    reference's other kwargs: what the reference would compute if its least_squares call
+    (bundle_adjustment.py:201-212) passed `loss`.  Also a tight dense run from that result."""
+    cam, feats, poses_cf0, lms_cf0, guesses, lm_guess = scene
+    n_poses = len(guesses)
+    args = (poses_cf0[0], n_poses, lm_guess.get_ids(), feats, cam)
+    mask = orc.sparsity_mask(n_poses, len(lm_guess.get_ids()), pk["obs_cam"], pk["obs_pt"])
+    a = (pk["pose0"], n_poses, pk["obs_cam"], pk["obs_pt"], pk["obs_uv"], pk["intr"])
+    out = {}
+    for loss in ROBUST_LOSSES:
+        res = ref_ba.least_squares(ref_ba.BundleAdjustment.residual_function, pk["x0"], jac_sparsity=mask,
+                                   method="trf", x_scale="jac", ftol=1e-6, xtol=1e-6, gtol=1e-6, max_nfev=2000,
+                                   loss=loss, f_scale=1.0, args=args)
+        pol = orc.polish(res.x, *a, dense=True, max_nfev=300, loss=loss, f_scale=1.0)
+        out[f"{loss}_ref_cost"] = np.array(res.cost)
+        out[f"{loss}_ref_x"] = res.x
+        out[f"{loss}_ref_status"] = np.array(res.status)
+        out[f"{loss}_ref_nfev"] = np.array(res.nfev)
+        out[f"{loss}_polished_cost"] = np.array(pol.cost)
+        out[f"{loss}_polished_x"] = pol.x
+        out[f"{loss}_cost_at_x0"] = np.array(orc.robust_cost(
+            ref_ba.BundleAdjustment.residual_function(pk["x0"], *args), loss, 1.0))
+        print(f"    {loss}: ref cost {res.cost:.12g} status {res.status} nfev {res.nfev}  polished {pol.cost:.12g}")
+    return out
+
+
 def polish(pk, res, dense):
     n_poses = (len(pk["poses_gt"]) - 1)
     a = (pk["pose0"], n_poses, pk["obs_cam"], pk["obs_pt"], pk["obs_uv"], pk["intr"])
@@ -241,20 +281,29 @@ def known_answers():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    only = set(sys.argv[1:])  # fixture names to (re)generate; none = all
     jobs = [
         ("test_scene_convergence", lambda: seeded_scene(TEST_POSES, 50, 0.2, 0.1, 0.05), True, True, False),
         ("test_scene_landmark_accuracy", lambda: seeded_scene(TEST_POSES, 50, 0.3, 0.05, 0.02), True, True, False),
         ("demo_scene", lambda: seeded_scene(DEMO_POSES, 100, 0.5, 0.5, 0.1), True, True, False),
         ("noisy_10x300", lambda: noisy_scene(10, 300), True, True, False),
         ("ring_50x2000", lambda: ring_scene(50, 2000, 10), False, False, True),
+        # radial distortion (src/camera.py:141-159) through the reference's optimize()
+        ("distorted_10x300", lambda: noisy_scene(10, 300, dist=(-0.28, 0.07, 0.01)), True, True, False),
+        # ... and gross outliers, for the robust losses (run_robust)
+        ("outliers_10x300", lambda: noisy_scene(10, 300, outlier_fraction=0.05), True, True, False),
     ]
     for name, make, shipped, dense, thin in jobs:
+        if only and name not in only:
+            continue
         t0 = time.time()
         scene = make()
         pk = pack(*scene)
         out, res = run_reference(scene, pk, shipped)
         out.update(polish(pk, res, dense))
         out["rms_reproj"] = np.array(orc.rms_reprojection(res.fun))
+        if name.startswith("outliers"):
+            out.update(run_robust(scene, pk))
         if thin:  # keep the file small: the product generator rebuilds the arrays, sampled values pin them
             full = dict(pk)
             sample = np.arange(0, len(full["obs_cam"]), 37)
@@ -269,8 +318,9 @@ def main():
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **pk, **out)
         print(f"{name}: ref cost {float(out['ref_cost']):.12g} status {int(out['ref_status'])} nfev "
               f"{int(out['ref_nfev'])}  polished {float(out['polished_cost']):.12g}  ({time.time() - t0:.1f}s)")
-    np.savez_compressed(os.path.join(OUT, "known_answers.npz"), **known_answers())
-    print("known_answers written")
+    if not only or "known_answers" in only:
+        np.savez_compressed(os.path.join(OUT, "known_answers.npz"), **known_answers())
+        print("known_answers written")
 
 
 if __name__ == "__main__":

@@ -245,9 +245,10 @@ def jacobian_packed(params, pose0, num_poses, obs_cam, obs_pt, obs_uv, intr) -> 
 
 # --------------------------------------------------------------------------- solves
 def solve_scipy_path(x0, pose0, num_poses, obs_cam, obs_pt, obs_uv, intr, num_landmarks: Optional[int] = None,
-                     max_nfev: Optional[int] = None):
+                     max_nfev: Optional[int] = None, loss: str = "linear", f_scale: float = 1.0):
     """The reference's optimiser call (bundle_adjustment.py:201-219) on packed arrays.
 
+    ``loss`` / ``f_scale`` are scipy's robust-loss hook, which the reference leaves at 'linear' / 1.0.
     Returns (OptimizeResult, seconds inside least_squares, seconds building the mask).
     """
     if num_landmarks is None:
@@ -258,21 +259,33 @@ def solve_scipy_path(x0, pose0, num_poses, obs_cam, obs_pt, obs_uv, intr, num_la
     kw = dict(REF_LSQ_KWARGS)
     if max_nfev is not None:
         kw["max_nfev"] = max_nfev
+    kw.update(loss=loss, f_scale=f_scale)
     res = least_squares(residual_packed, x0, jac_sparsity=mask,
                         args=(pose0, num_poses, np.asarray(obs_cam), np.asarray(obs_pt), obs_uv, intr), **kw)
     t2 = time.perf_counter()
     return res, t2 - t1, t1 - t0
 
 
-def polish(x_start, pose0, num_poses, obs_cam, obs_pt, obs_uv, intr, dense: bool, max_nfev: int = 200):
+def polish(x_start, pose0, num_poses, obs_cam, obs_pt, obs_uv, intr, dense: bool, max_nfev: int = 200,
+           loss: str = "linear", f_scale: float = 1.0):
     """Tight-tolerance minimum used as the two-sided cost oracle."""
     args = (pose0, num_poses, np.asarray(obs_cam), np.asarray(obs_pt), obs_uv, intr)
     if dense:
         return least_squares(residual_packed, x_start, method="trf", x_scale="jac", ftol=1e-15, xtol=1e-15,
-                             gtol=1e-12, max_nfev=max_nfev, args=args)
+                             gtol=1e-12, max_nfev=max_nfev, args=args, loss=loss, f_scale=f_scale)
     return least_squares(residual_packed, x_start, jac=jacobian_packed, method="trf", x_scale="jac",
                          tr_solver="lsmr", tr_options={"atol": 1e-12, "btol": 1e-12},
-                         ftol=1e-14, xtol=1e-14, gtol=1e-12, max_nfev=max_nfev, args=args)
+                         ftol=1e-14, xtol=1e-14, gtol=1e-12, max_nfev=max_nfev, args=args, loss=loss, f_scale=f_scale)
+
+
+def robust_cost(residuals: np.ndarray, loss: str = "linear", f_scale: float = 1.0) -> float:
+    """scipy's cost for a residual vector: 0.5 * f_scale^2 * sum rho((f / f_scale)^2)
+    (scipy/optimize/_lsq/least_squares.py:186-236)."""
+    z = (np.asarray(residuals) / f_scale) ** 2
+    rho = {"linear": lambda z: z, "soft_l1": lambda z: 2 * (np.sqrt(1 + z) - 1),
+           "huber": lambda z: np.where(z <= 1, z, 2 * np.sqrt(np.maximum(z, 1e-300)) - 1),
+           "cauchy": np.log1p, "arctan": np.arctan}[loss](z)
+    return float(0.5 * f_scale**2 * np.sum(rho))
 
 
 def rms_reprojection(residuals: np.ndarray) -> float:

@@ -8,7 +8,7 @@ import pytest
 from src.bundle_adjustment import BundleAdjustment
 from src.camera import PinHoleCamera
 from src.camera_pose import CameraPose
-from src.feature_observation import ImageFeatures, Landmarks3D
+from src.feature_observation import Features2D, ImageFeatures, Landmarks3D
 from src.geometry import GeometryUtils
 from src.landmarks import LandmarkGenerator
 
@@ -117,3 +117,44 @@ def test_residual_function_and_sparsity_api(synthetic_data, golden):
     A = BundleAdjustment.bundle_adjustment_sparsity(3, 50, d["image_features"]).tocsr()
     A.sort_indices()
     assert np.array_equal(A.indptr, g["mask_indptr"]) and np.array_equal(A.indices, g["mask_indices"])
+
+
+def _from_fixture(g):
+    C = len(g["poses_gt"])
+    cam = PinHoleCamera(*(float(v) for v in g["intr"]))
+    feats = []
+    for c in range(C):
+        sel = g["obs_cam"] == c
+        feats.append(ImageFeatures(float(g["timestamps"][c]), 640, 480, 0,
+                                   Features2D(g["obs_uv"][sel], g["landmark_ids"][g["obs_pt"][sel]])))
+    pose0 = CameraPose(position=g["pose0"][:3], orientation=g["pose0"][3:7], timestamp=float(g["timestamps"][0]))
+    x0 = g["x0"]
+    guesses = [CameraPose(position=x0[7 * i: 7 * i + 3], orientation=x0[7 * i + 3: 7 * i + 7] /
+                          np.linalg.norm(x0[7 * i + 3: 7 * i + 7]), timestamp=float(g["timestamps"][i + 1]))
+               for i in range(C - 1)]
+    return cam, feats, pose0, guesses, Landmarks3D(x0[7 * (C - 1):].reshape(-1, 3), g["landmark_ids"])
+
+
+def test_distorted_camera_through_the_entry_point(golden):
+    """a camera with k1, k2, k3 != 0 (reference src/camera.py:141-159) through
+    optimize(); the returned re-projections against those the reference's optimize() returned
+    (fixture opt_uv; both stop at their own tolerances: 0.02 px), and the cost against the polished one."""
+    g = golden("distorted_10x300")
+    cam, feats, pose0, guesses, lms = _from_fixture(g)
+    assert cam.k1 != 0 and cam.k2 != 0 and cam.k3 != 0
+    ba = BundleAdjustment()
+    opt_feats, opt_pts, opt_poses = ba.optimize(feats, pose0, cam, guesses, lms)
+    uv = np.vstack([f.get_points_2d().get_points_2d() for f in opt_feats])
+    assert np.abs(uv - g["opt_uv"]).max() < 0.02
+    assert abs(ba.last_report["cost"] - float(g["polished_cost"])) <= 1e-6 * float(g["polished_cost"])
+
+
+def test_robust_loss_option_through_the_entry_point(golden):
+    """BundleAdjustment(loss=..., f_scale=...) -- the names of scipy's least_squares arguments -- reaches
+    the tight-tolerance Huber minimum recorded with the reference's residual function."""
+    g = golden("outliers_10x300")
+    cam, feats, pose0, guesses, lms = _from_fixture(g)
+    ba = BundleAdjustment(loss="huber", f_scale=1.0)
+    ba.optimize(feats, pose0, cam, guesses, lms)
+    pol = float(g["huber_polished_cost"])
+    assert abs(ba.last_report["cost"] - pol) <= 1e-6 * pol

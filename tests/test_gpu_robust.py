@@ -1,0 +1,179 @@
+"""GPU parity tests for SURVEY.md section 8 (f1): radial distortion (reference src/camera.py:141-159)
+and the robust losses of scipy's `loss=` hook, through the C ABI, against fixtures recorded from the
+reference (tests/golden/distorted_10x300.npz, outliers_10x300.npz) and the numpy oracle."""
+
+import numpy as np
+import pytest
+
+from oracle import lm_schur_numpy as lm
+from oracle import ref_scipy_path as orc
+from src import _native
+from src.validation_error import ValidationError
+
+pytestmark = pytest.mark.gpu
+
+ROBUST = ["soft_l1", "huber", "cauchy", "arctan"]
+
+
+def _state(g):
+    n_poses = len(g["poses_gt"]) - 1
+    poses = np.vstack([g["pose0"][None], g["x0"][: 7 * n_poses].reshape(-1, 7)])
+    pts = g["x0"][7 * n_poses:].reshape(-1, 3)
+    return n_poses, poses, pts
+
+
+def _solver(g, **opt):
+    s = _native.Solver(**opt)
+    s.set_problem(len(g["poses_gt"]), len(g["landmark_ids"]), g["obs_cam"], g["obs_pt"], g["obs_uv"], g["intr"])
+    return s
+
+
+def _close(a, b, tol=1e-10):
+    np.testing.assert_allclose(a, b, rtol=0, atol=tol * max(np.abs(b).max(), 1e-300))
+
+
+def test_distorted_residuals_and_jacobians(golden):
+    """Residuals vs the reference's residual_function (1e-9 px); analytic blocks vs central differences
+    of the reference-path residual (1e-6 relative) and vs the numpy blocks (1e-11)."""
+    g = golden("distorted_10x300")
+    n_poses, poses, pts = _state(g)
+    C = n_poses + 1
+    a = (g["pose0"], n_poses, g["obs_cam"], g["obs_pt"], g["obs_uv"], g["intr"])
+    with _solver(g) as s:
+        r, cost, _ = s.evaluate(poses, pts)
+        Jc, Jp = s.jacobian_blocks(poses, pts)
+        xr = g["ref_x"]
+        r2, _, _ = s.evaluate(np.vstack([g["pose0"][None], xr[: 7 * n_poses].reshape(-1, 7)]),
+                              xr[7 * n_poses:].reshape(-1, 3))
+    np.testing.assert_allclose(r, g["residual_at_x0"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(r2, g["ref_residual"], rtol=0, atol=1e-9)
+    _, Jc_o, Jp_o = lm.linearize(poses, pts, g["obs_cam"], g["obs_pt"], g["obs_uv"], g["intr"])
+    Jc_o[g["obs_cam"] == 0] = 0.0
+    _close(Jc, Jc_o, 1e-11)
+    _close(Jp, Jp_o, 1e-11)
+    free = np.ones(C, bool)
+    free[0] = False
+
+    def res_at(poses_, pts_):
+        return orc.residual_packed(np.concatenate([poses_[1:].reshape(-1), pts_.reshape(-1)]), *a).reshape(-1, 2)
+
+    h = 1e-6
+    for cam in (1, C - 1):
+        sel = g["obs_cam"] == cam
+        for k in range(6):
+            d = np.zeros((C, 6))
+            d[cam, k] = h
+            fd = (res_at(lm.retract(poses, d, free), pts) - res_at(lm.retract(poses, -d, free), pts)) / (2 * h)
+            assert np.abs(Jc[sel][:, :, k] - fd[sel]).max() <= 1e-6 * np.abs(fd[sel]).max()
+    for lmk in (0, len(pts) - 1):
+        sel = g["obs_pt"] == lmk
+        for k in range(3):
+            d = np.zeros_like(pts)
+            d[lmk, k] = h
+            fd = (res_at(poses, pts + d) - res_at(poses, pts - d)) / (2 * h)
+            assert np.abs(Jp[sel][:, :, k] - fd[sel]).max() <= 1e-6 * np.abs(fd[sel]).max()
+
+
+def test_distorted_converged_cost_matches_reference(golden):
+    """Converged cost with k1, k2, k3 != 0: one-sided against the reference's optimize(), two-sided
+    (1e-6 relative) against the tight-tolerance minimum."""
+    g = golden("distorted_10x300")
+    n_poses, poses, pts = _state(g)
+    with _solver(g) as s:
+        P, X, rep = s.solve(poses, pts)
+        _, cost_check, _ = s.evaluate(P, X, want_residuals=False)
+    ref, pol = float(g["ref_cost"]), float(g["polished_cost"])
+    assert abs(rep["cost"] - cost_check) <= 1e-12 * pol
+    assert rep["cost"] <= ref * (1 + 1e-6)
+    assert abs(rep["cost"] - pol) <= 1e-6 * pol, (rep["cost"], pol)
+
+
+@pytest.mark.parametrize("loss", ROBUST)
+def test_robust_blocks_match_oracle(golden, loss):
+    """Robust cost at x0 vs the value recorded from the reference's residuals (1e-12 relative); the
+    re-weighted U, V, W, gradients, S, rhs and LM step vs the numpy restatement."""
+    g = golden("outliers_10x300")
+    n_poses, poses, pts = _state(g)
+    C, L = n_poses + 1, len(pts)
+    lam = 1e-3
+    with _solver(g, loss=loss, f_scale=1.0, pcg_tol=1e-13, pcg_max_iter=2000) as s:
+        r, cost, _ = s.evaluate(poses, pts)
+        out = s.debug_linearization(poses, pts, lam)
+        Jc_raw, _ = s.jacobian_blocks(poses, pts)
+    np.testing.assert_allclose(r, g["residual_at_x0"], rtol=0, atol=1e-9)  # residuals stay unweighted
+    c0 = float(g[f"{loss}_cost_at_x0"])
+    assert abs(cost - c0) <= 1e-12 * c0
+    rr, Jc, Jp = lm.linearize(poses, pts, g["obs_cam"], g["obs_pt"], g["obs_uv"], g["intr"])
+    free = np.ones(C, bool)
+    free[0] = False
+    Jc = Jc * free[g["obs_cam"]][:, None, None]
+    _close(Jc_raw, Jc, 1e-11)  # the exported blocks are never re-weighted
+    rr, Jc, Jp, cost_o = lm.robustify(rr, Jc, Jp, loss, 1.0)
+    assert abs(cost - cost_o) <= 1e-12 * cost_o
+    U, V, W, gc, gp, _ = lm.normal_blocks(rr, Jc, Jp, g["obs_cam"], g["obs_pt"], C, L)
+    for k, ref in (("U", U), ("V", V), ("W", W), ("gc", gc), ("gp", gp)):
+        _close(out[k], ref)
+    S, rhs, Vi = lm.schur_system(U, V, W, gc, gp, g["obs_cam"], g["obs_pt"], lam, free)
+    _close(out["S"], S, 1e-9)
+    _close(out["rhs"], rhs, 1e-9)
+    dc = np.linalg.solve(S, -rhs).reshape(C, 6) * free[:, None]
+    dp = lm.back_substitute(dc, Vi, W, gp, g["obs_cam"], g["obs_pt"], L)
+    _close(out["dc"], dc, 1e-7)
+    _close(out["dp"], dp, 1e-7)
+
+
+@pytest.mark.parametrize("loss", ROBUST)
+def test_robust_converged_cost(golden, loss):
+    """Converged robust cost from the outlier-laden guess: never above scipy's result at the reference's
+    tolerances (driven by the reference's residual_function); within 1e-6 relative of the
+    tight-tolerance minimum for soft_l1 and huber; for cauchy and arctan (several local minima on this
+    scene, so the minimiser is unpinned) at or below it, and equal to the numpy oracle's when both take
+    exact steps."""
+    g = golden("outliers_10x300")
+    n_poses, poses, pts = _state(g)
+    with _solver(g, loss=loss, f_scale=1.0, max_iters=200) as s:
+        P, X, rep = s.solve(poses, pts)
+        _, cost_check, _ = s.evaluate(P, X, want_residuals=False)
+    ref, pol = float(g[f"{loss}_ref_cost"]), float(g[f"{loss}_polished_cost"])
+    assert abs(rep["cost0"] - float(g[f"{loss}_cost_at_x0"])) <= 1e-12 * rep["cost0"]
+    assert abs(rep["cost"] - cost_check) <= 1e-12 * max(pol, rep["cost"])
+    assert rep["status"] != 0, rep
+    assert rep["cost"] <= ref * (1 + 1e-6)
+    if loss in ("soft_l1", "huber"):
+        assert abs(rep["cost"] - pol) <= 1e-6 * pol, (rep["cost"], pol)
+    else:
+        assert rep["cost"] <= pol * (1 + 1e-6), (rep["cost"], pol)
+        # same algorithm, exact linear solves on both sides: the GPU follows the numpy restatement's path
+        # into the same local minimum (an inexact PCG step is enough to end in a different one)
+        with _solver(g, loss=loss, f_scale=1.0, max_iters=500, ftol=1e-12, linear_solver=2) as s:
+            _, _, rep2 = s.solve(poses, pts)
+        _, _, orep = lm.lm_solve(poses, pts, g["obs_cam"], g["obs_pt"], g["obs_uv"], g["intr"],
+                                 opt=lm.LMOptions(loss=loss, max_iters=500, ftol=1e-12))
+        assert abs(rep2["cost"] - orep.cost) <= 1e-9 * orep.cost, (rep2["cost"], orep.cost)
+        assert rep2["cost"] <= pol * (1 + 1e-6)
+
+
+def test_huber_recovers_inlier_geometry(golden):
+    """With 5 % gross outliers the plain least-squares estimate is dragged away; the Huber estimate
+    stays at the ground truth to the level of the outlier-free scene (same inlier pixels)."""
+    g = golden("outliers_10x300")
+    n_poses, poses, pts = _state(g)
+
+    def err(X, P):
+        scale = np.sum(g["points_gt"] * X) / np.sum(X * X)
+        return np.abs(X * scale - g["points_gt"]).max()
+
+    with _solver(g) as s:
+        P0, X0, rep0 = s.solve(poses, pts)
+    with _solver(g, loss="huber", f_scale=1.0) as s:
+        P1, X1, rep1 = s.solve(poses, pts)
+    assert err(X1, P1) < 0.2 * err(X0, P0), (err(X1, P1), err(X0, P0))
+
+
+def test_loss_option_validation():
+    with pytest.raises(ValidationError):
+        _native.Solver(loss="tukey")
+    with pytest.raises(ValidationError):
+        _native.Solver(loss=9)
+    with pytest.raises(ValidationError):
+        _native.Solver(loss="huber", f_scale=0.0)

@@ -7,7 +7,9 @@ import pytest
 from oracle import lm_schur_numpy as lm
 from oracle import ref_scipy_path as orc
 
-SMALL = ["test_scene_convergence", "test_scene_landmark_accuracy", "demo_scene", "noisy_10x300"]
+SMALL = ["test_scene_convergence", "test_scene_landmark_accuracy", "demo_scene", "noisy_10x300",
+         "distorted_10x300", "outliers_10x300"]
+ROBUST = ["soft_l1", "huber", "cauchy", "arctan"]
 
 
 def _args(g):
@@ -43,7 +45,8 @@ def test_sparsity_mask_matches_reference(golden, name):
     assert m.nnz == 2 * nobs * 10 - 2 * nobs0 * 7
 
 
-@pytest.mark.parametrize("name", ["test_scene_convergence", "test_scene_landmark_accuracy", "noisy_10x300"])
+@pytest.mark.parametrize("name", ["test_scene_convergence", "test_scene_landmark_accuracy", "noisy_10x300",
+                                  "distorted_10x300"])
 def test_scipy_path_reproduces_reference_solution(golden, name):
     g = golden(name)
     n_poses, a = _args(g)
@@ -55,7 +58,9 @@ def test_scipy_path_reproduces_reference_solution(golden, name):
         # reference vs explicit sums here) pass through finite differences and an inexact LSMR
         # step: agreement is 1e-8 relative, asserted at 1e-7 (north_star bar: 1e-6)
         assert abs(res.cost - float(g["ref_cost"])) <= 1e-7 * float(g["ref_cost"])
-        np.testing.assert_allclose(res.x, g["ref_x"], rtol=0, atol=1e-5)
+        # x: both runs stop at ftol 1e-6 on a valley that is flat along the free scale; 1.7e-5 on the
+        # distorted scene, below 1e-5 on the others
+        np.testing.assert_allclose(res.x, g["ref_x"], rtol=0, atol=5e-5 if name == "distorted_10x300" else 1e-5)
     else:  # noise-free scene: cost ~ 0, compare absolutely
         assert res.cost < 1e-9
 
@@ -110,7 +115,7 @@ def test_local_jacobian_vs_finite_differences(golden):
             assert np.abs(Jp[sel][:, :, k] - fd[sel]).max() <= 1e-6 * scale
 
 
-@pytest.mark.parametrize("name", ["noisy_10x300"])
+@pytest.mark.parametrize("name", ["noisy_10x300", "distorted_10x300"])
 def test_lm_oracle_reaches_polished_minimum(golden, name):
     g = golden(name)
     n_poses, a = _args(g)
@@ -120,3 +125,82 @@ def test_lm_oracle_reaches_polished_minimum(golden, name):
     pol = float(g["polished_cost"])
     assert abs(rep.cost - pol) <= 1e-6 * pol
     assert rep.cost <= float(g["ref_cost"]) * (1 + 1e-6)
+
+
+def test_distorted_jacobian_vs_finite_differences(golden):
+    """Blocks of the LM oracle with radial distortion (src/camera.py:141-159) against central differences
+    of the reference-path residual."""
+    g = golden("distorted_10x300")
+    assert np.all(g["intr"][4:7] != 0)
+    n_poses, a = _args(g)
+    C = n_poses + 1
+    poses = np.vstack([g["pose0"][None], g["x0"][: 7 * n_poses].reshape(-1, 7)])
+    pts = g["x0"][7 * n_poses:].reshape(-1, 3)
+    r, Jc, Jp = lm.linearize(poses, pts, g["obs_cam"], g["obs_pt"], g["obs_uv"], g["intr"])
+    np.testing.assert_allclose(r.reshape(-1), g["residual_at_x0"], rtol=0, atol=1e-9)
+    free = np.ones(C, bool)
+    free[0] = False
+
+    def res_at(poses_, pts_):
+        return orc.residual_packed(np.concatenate([poses_[1:].reshape(-1), pts_.reshape(-1)]), *a).reshape(-1, 2)
+
+    h = 1e-6
+    for cam in (1, C - 1):
+        sel = g["obs_cam"] == cam
+        for k in range(6):
+            d = np.zeros((C, 6))
+            d[cam, k] = h
+            fd = (res_at(lm.retract(poses, d, free), pts) - res_at(lm.retract(poses, -d, free), pts)) / (2 * h)
+            assert np.abs(Jc[sel][:, :, k] - fd[sel]).max() <= 1e-6 * np.abs(fd[sel]).max()
+    for lmk in (0, 123):
+        sel = g["obs_pt"] == lmk
+        for k in range(3):
+            d = np.zeros_like(pts)
+            d[lmk, k] = h
+            fd = (res_at(poses, pts + d) - res_at(poses, pts - d)) / (2 * h)
+            assert np.abs(Jp[sel][:, :, k] - fd[sel]).max() <= 1e-6 * np.abs(fd[sel]).max()
+
+
+@pytest.mark.parametrize("loss", ROBUST)
+def test_robust_loss_functions_match_scipy(golden, loss):
+    """rho, rho', rho'' and the cost against scipy's own loss implementations (the third-party code the
+    reference's least_squares call would run with loss=...), and against the cost recorded from the
+    reference's residual_function at x0."""
+    from scipy.optimize._lsq.least_squares import construct_loss_function
+
+    g = golden("outliers_10x300")
+    f = g["residual_at_x0"].copy()
+    for f_scale in (1.0, 2.5):
+        rho = construct_loss_function(len(f), loss, f_scale)(f)  # rows: rho * C^2, rho', rho'' / C^2
+        z = (f / f_scale) ** 2
+        r0, r1, r2 = lm.rho_functions(loss, z)
+        np.testing.assert_allclose(r0 * f_scale**2, rho[0], rtol=1e-14, atol=0)
+        np.testing.assert_allclose(r1, rho[1], rtol=1e-14, atol=0)
+        np.testing.assert_allclose(r2 / f_scale**2, rho[2], rtol=1e-13, atol=1e-300)
+        assert abs(orc.robust_cost(f, loss, f_scale) - 0.5 * rho[0].sum()) <= 1e-13 * rho[0].sum()
+        rs, _, _, cost = lm.robustify(f.reshape(-1, 2), None, None, loss, f_scale)
+        assert abs(cost - 0.5 * rho[0].sum()) <= 1e-13 * rho[0].sum()
+        # gradient of the robust cost wrt f is f rho'; the re-weighted pair (s f, s J) reproduces it: s * (s f)
+        np.testing.assert_allclose(np.sqrt(r1) * rs.reshape(-1), f * rho[1], rtol=1e-13, atol=0)
+    assert abs(orc.robust_cost(f, loss, 1.0) - float(g[f"{loss}_cost_at_x0"])) <= 1e-12 * float(g[f"{loss}_cost_at_x0"])
+
+
+@pytest.mark.parametrize("loss", ROBUST)
+def test_lm_oracle_robust_minimum(golden, loss):
+    """The LM restatement with a robust loss against scipy driven by the reference's residual function
+    (fixture): never above the reference-tolerance result; equal to the tight-tolerance minimum for the
+    two losses with a unique minimum here (soft_l1, huber); at or below it for the non-convex ones
+    (cauchy, arctan have several local minima on this scene: parity of the minimiser is unpinned there)."""
+    g = golden("outliers_10x300")
+    n_poses, a = _args(g)
+    poses = np.vstack([g["pose0"][None], g["x0"][: 7 * n_poses].reshape(-1, 7)])
+    pts = g["x0"][7 * n_poses:].reshape(-1, 3)
+    _, _, rep = lm.lm_solve(poses, pts, g["obs_cam"], g["obs_pt"], g["obs_uv"], g["intr"],
+                            opt=lm.LMOptions(loss=loss, max_iters=200))
+    ref, pol = float(g[f"{loss}_ref_cost"]), float(g[f"{loss}_polished_cost"])
+    assert abs(rep.cost0 - float(g[f"{loss}_cost_at_x0"])) <= 1e-12 * rep.cost0
+    assert rep.cost <= ref * (1 + 1e-6)
+    if loss in ("soft_l1", "huber"):
+        assert abs(rep.cost - pol) <= 1e-6 * pol, (rep.cost, pol)
+    else:
+        assert rep.cost <= pol * (1 + 1e-6), (rep.cost, pol)

@@ -39,33 +39,31 @@ __device__ __forceinline__ double robust_cost(const RobustLoss& l, double f) {
   return 0.5 * l.c2 * rho;
 }
 
-// Triggs' correction as scipy applies it (scipy/optimize/_lsq/common.py:scale_for_robust_loss_function):
-// the Jacobian row of f is multiplied by s = sqrt(max(rho' + 2 rho'' z, eps)) and f becomes f rho' / s, so
-// that J^T f is the gradient of the robust cost and J^T J its Gauss-Newton Hessian.  Returns the cost term.
+// Re-weighting of one scalar residual for the linearisation: f and its Jacobian row are both multiplied
+// by s = sqrt(rho'(z)), so that J^T f is the gradient of the robust cost and J^T J = J^T rho' J majorises its
+// Hessian (every rho here is concave in z).  scipy adds Triggs' second-order term, s^2 = max(rho' + 2 rho'' z,
+// eps) (scipy/optimize/_lsq/common.py:scale_for_robust_loss_function); with that clamp the rows of outliers
+// vanish from J^T J and from the Marquardt diagonal and LM rejects every step from a poor guess, so only the
+// first-order weight is kept: same objective and minimisers, different Gauss-Newton model.
+// Returns the cost term 0.5 C^2 rho(z).
 __device__ __forceinline__ double robust_scale(const RobustLoss& l, double& f, double& s) {
   const double z = f * f * l.inv_c2;
-  double rho, r1, r2z;  // r2z = rho'' * z
+  double rho, r1;
   switch (l.kind) {
     case LOSS_SOFT_L1: {
       const double t = 1.0 + z, it = 1.0 / sqrt(t);
-      rho = 2.0 * (t * it - 1.0); r1 = it; r2z = -0.5 * it / t * z;
+      rho = 2.0 * (t * it - 1.0); r1 = it;
     } break;
     case LOSS_HUBER:
-      if (z <= 1.0) { rho = z; r1 = 1.0; r2z = 0.0; }
-      else { const double iz = 1.0 / sqrt(z); rho = 2.0 * z * iz - 1.0; r1 = iz; r2z = -0.5 * iz; }
+      if (z <= 1.0) { rho = z; r1 = 1.0; }
+      else { const double iz = 1.0 / sqrt(z); rho = 2.0 * z * iz - 1.0; r1 = iz; }
       break;
-    case LOSS_CAUCHY: {
-      const double it = 1.0 / (1.0 + z);
-      rho = log1p(z); r1 = it; r2z = -it * it * z;
-    } break;
-    case LOSS_ARCTAN: {
-      const double it = 1.0 / (1.0 + z * z);
-      rho = atan(z); r1 = it; r2z = -2.0 * z * it * it * z;
-    } break;
-    default: rho = z; r1 = 1.0; r2z = 0.0;
+    case LOSS_CAUCHY: rho = log1p(z); r1 = 1.0 / (1.0 + z); break;
+    case LOSS_ARCTAN: rho = atan(z); r1 = 1.0 / (1.0 + z * z); break;
+    default: rho = z; r1 = 1.0;
   }
-  s = sqrt(fmax(r1 + 2.0 * r2z, 2.220446049250313e-16));
-  f *= r1 / s;
+  s = sqrt(r1);
+  f *= s;
   return 0.5 * l.c2 * rho;
 }
 

@@ -143,6 +143,9 @@ class Solver:
         rc = lib.ba_create(C.byref(self.opt), C.byref(self._h))
         if rc != 0:
             self._h = None
+            if rc == 1:
+                raise ValidationError("ba_create rejected the options (loss must be a ba_loss value, f_scale > 0, "
+                                      "device an existing ordinal)")
             raise RuntimeError(f"ba_create failed with status {rc}: no usable MI355X / HIP device "
                                "(the solver has no CPU fallback)")
         self.C = self.L = self.n = 0
