@@ -126,8 +126,10 @@ constexpr int SCHUR_STRIDE = 37;  // 36 values + pad
 #ifndef LIN_WAVES
 #define LIN_WAVES 2
 #endif
-template <int G>
-__global__ __launch_bounds__(64, LIN_WAVES) void k_linearize(DeviceProblem d, const double* __restrict__ poses,
+// ROBUST: compile the re-weighting of a robust loss in (a run-time branch costs the plain kernel registers
+// it does not have: 78 spilled VGPRs, 24.5 -> 29.4 us at BASELINE configs[1]).
+template <int G, bool ROBUST>
+__global__ __launch_bounds__(64, ROBUST ? 1 : LIN_WAVES) void k_linearize(DeviceProblem d, const double* __restrict__ poses,
                                                   const double* __restrict__ pts, int lm_per_group) {
   __shared__ double stage[64 * LIN_STRIDE];
   if (poses == nullptr) {  // solver mode: state and the run / skip decision come from the device-side LM control
@@ -202,9 +204,9 @@ __global__ __launch_bounds__(64, LIN_WAVES) void k_linearize(DeviceProblem d, co
         linearize_obs(d.K, poses + 7 * cam, P, first ? u_first : d.o_u[k], first ? v_first : d.o_v[k], r, Jc, Jp, zc);
         nbehind += (zc <= 0.0);
         nzero += (zc == 0.0);
-        if (d.loss.kind == LOSS_LINEAR) {
+        if (!ROBUST) {
           cost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
-        } else {  // robust loss: scale each residual and its Jacobian row (wave-uniform branch)
+        } else {  // robust loss: scale each residual and its Jacobian row
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             double s;
@@ -271,6 +273,7 @@ __global__ __launch_bounds__(64, LIN_WAVES) void k_linearize(DeviceProblem d, co
 // ------------------------------------------------------------------------------------------------
 // k_cost: residuals only (trial-point evaluation, ba_evaluate).  24 B/obs (+ cached P, pose).
 // Flat over observations; the landmark of observation k is found from o_lm[k].
+template <bool ROBUST>
 __global__ __launch_bounds__(256) void k_cost(DeviceProblem d,
                                               const double* __restrict__ poses, const double* __restrict__ pts,
                                               int cost_slot, int behind_slot, double* __restrict__ res_out) {
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(256) void k_cost(DeviceProblem d,
     reproject(d.K, X, d.o_u[k], d.o_v[k], r0, r1);
     nbehind += (X[2] <= 0.0);
     nzero += (X[2] == 0.0);
-    cost += d.loss.kind == LOSS_LINEAR ? 0.5 * (r0 * r0 + r1 * r1) : robust_cost(d.loss, r0) + robust_cost(d.loss, r1);
+    cost += !ROBUST ? 0.5 * (r0 * r0 + r1 * r1) : robust_cost(d.loss, r0) + robust_cost(d.loss, r1);
     if (res_out) {
       const long s = d.o_src[k];
       res_out[2 * s] = r0;

@@ -243,11 +243,20 @@ void launch_linearize(ba_handle* h, const double* poses, const double* pts) {
   const DeviceProblem& d = h->d;
   const int G = h->g_lin, lpg = h->lpg_lin;
   const int grid = grid_for(d.L_obs, (64 / G) * lpg);
-  switch (G) {
-    case 8: launch_timed(h, KT_LIN, k_linearize<8>, grid, 64, d, poses, pts, lpg); break;
-    case 16: launch_timed(h, KT_LIN, k_linearize<16>, grid, 64, d, poses, pts, lpg); break;
-    case 32: launch_timed(h, KT_LIN, k_linearize<32>, grid, 64, d, poses, pts, lpg); break;
-    default: launch_timed(h, KT_LIN, k_linearize<64>, grid, 64, d, poses, pts, lpg); break;
+  if (d.loss.kind == LOSS_LINEAR) {
+    switch (G) {
+      case 8: launch_timed(h, KT_LIN, k_linearize<8, false>, grid, 64, d, poses, pts, lpg); break;
+      case 16: launch_timed(h, KT_LIN, k_linearize<16, false>, grid, 64, d, poses, pts, lpg); break;
+      case 32: launch_timed(h, KT_LIN, k_linearize<32, false>, grid, 64, d, poses, pts, lpg); break;
+      default: launch_timed(h, KT_LIN, k_linearize<64, false>, grid, 64, d, poses, pts, lpg); break;
+    }
+  } else {
+    switch (G) {
+      case 8: launch_timed(h, KT_LIN, k_linearize<8, true>, grid, 64, d, poses, pts, lpg); break;
+      case 16: launch_timed(h, KT_LIN, k_linearize<16, true>, grid, 64, d, poses, pts, lpg); break;
+      case 32: launch_timed(h, KT_LIN, k_linearize<32, true>, grid, 64, d, poses, pts, lpg); break;
+      default: launch_timed(h, KT_LIN, k_linearize<64, true>, grid, 64, d, poses, pts, lpg); break;
+    }
   }
 }
 
@@ -293,7 +302,10 @@ void launch_schur(ba_handle* h, double lam) {
 void launch_cost(ba_handle* h, const double* poses, const double* pts, int cost_slot, int behind_slot,
                  double* res_out) {
   const int grid = std::min(grid_for(h->d.n), 256 * 16);
-  launch_timed(h, KT_COST, k_cost, grid, 256, h->d, poses, pts, cost_slot, behind_slot, res_out);
+  if (h->d.loss.kind == LOSS_LINEAR)
+    launch_timed(h, KT_COST, k_cost<false>, grid, 256, h->d, poses, pts, cost_slot, behind_slot, res_out);
+  else
+    launch_timed(h, KT_COST, k_cost<true>, grid, 256, h->d, poses, pts, cost_slot, behind_slot, res_out);
 }
 
 // One allocation holds [Ugc slabs | scalar copies | S slabs]: a linearising iteration clears all of it
