@@ -181,6 +181,22 @@ int ba_solve_batched(ba_handle* h, int32_t n_problems, const int32_t* cam_off, c
 int ba_evaluate(ba_handle* h, const double* poses, const double* points, double* residuals, double* cost,
                 int32_t* n_behind);
 
+/* Multi-view triangulation of every landmark of the current problem from KNOWN poses: the step on the
+ * input side of the path (initial points for ba_solve).  For two views this is what
+ * VisualOdometry.triangulate_points computes (visual_odometry.py:508-570: cv2.triangulatePoints, the linear
+ * DLT estimate, then (e1 + e2) / 2 as reprojection error); here for any number of views of a landmark, and
+ * with refine_iters > 0 followed by that many Gauss-Newton steps on the reprojection error at most (stops
+ * at |step| < 1e-6), the refinement initialization.triangulate_landmark sketches (initialization.py:96-143).
+ *   poses[C*7]     in, all held constant (quaternions are normalised)
+ *   points[L*3]    out: written for landmarks flagged valid, others left untouched
+ *   reproj_err[L]  out (may be NULL): mean pixel distance over the landmark's views; NaN if it has < 2 views
+ *   valid[L]       out (may be NULL): 1 = at least 2 views, finite, and deeper than min_depth in every view
+ *                  (initialization.py:148-155 uses 0.1; add_pts3d_to_map, visual_odometry.py:483-485, uses 0)
+ * Radial distortion: pixels are undistorted for the linear estimate; the refinement and the error use the
+ * full camera model.  Uses the trial buffers of the handle: a following ba_download_estimate needs a new solve. */
+int ba_triangulate(ba_handle* h, const double* poses, int32_t refine_iters, double min_depth, double* points,
+                   double* reproj_err, uint8_t* valid);
+
 /* Analytic Jacobian blocks in the caller's observation order: Jc[n_obs*12] = d r / d(dt, dtheta)
  * (2x6 row-major, zero for fixed poses), Jp[n_obs*6] = d r / dP (2x3).  The reference has no analytic
  * Jacobian (scipy differentiates numerically, scipy/optimize/_numdiff.py); exported so tests can check

@@ -279,6 +279,23 @@ def known_answers():
                     ([3.0, 0.1, 0.2], [0.1, 3.0, 0.2], [0.1, 0.2, 3.0], [0.1, 0.2, 0.3])]))
 
 
+def triangulation_known_answer():
+    """The scene of the reference's tests/test_triangulation.py:16-131 built with the reference's classes:
+    8 landmarks, two poses, noise-free pixels.  The reference asserts |triangulated - landmarks| < 1e-6 and
+    |reprojection error| < 1e-6 (:130-131); VisualOdometry.triangulate_points itself needs cv2 (absent in
+    this image), so the expected output recorded here is the one the reference's test demands."""
+    landmarks = np.array([[2.0773956, -0.37188637, 0.05458479], [2.04388784, -0.04961406, -0.43618274],
+                          [2.08585979, -0.12920198, 0.32763117], [2.0697368, 0.42676499, 0.1316644],
+                          [2.00941773, 0.14386512, 0.25808774], [2.09756224, 0.32276161, -0.14547403],
+                          [2.07611397, -0.0565858, 0.47069802], [2.07860643, -0.27276128, 0.39312112]])
+    poses = listed_poses([([0.0, 0.2, 0.0], [0.02, 0.03, 0.0], 0.0), ([0.0, 0.3, -0.3], [0.08, 0.3, 0.7], 3.0)])
+    cam = PinHoleCamera(fx=500.0, fy=500.0, cx=320.0, cy=240.0)
+    uv = np.stack([cam.project(p.transform_points_world_to_camera(landmarks)) for p in poses])
+    return dict(tri_landmarks=landmarks, tri_poses=np.array([np.concatenate([p.position, p.quaternion]) for p in poses]),
+                tri_intr=cam.to_vector(), tri_uv=uv,
+                tri_rot=np.stack([p.rotation_matrix for p in poses]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])  # fixture names to (re)generate; none = all
@@ -319,7 +336,7 @@ def main():
         print(f"{name}: ref cost {float(out['ref_cost']):.12g} status {int(out['ref_status'])} nfev "
               f"{int(out['ref_nfev'])}  polished {float(out['polished_cost']):.12g}  ({time.time() - t0:.1f}s)")
     if not only or "known_answers" in only:
-        np.savez_compressed(os.path.join(OUT, "known_answers.npz"), **known_answers())
+        np.savez_compressed(os.path.join(OUT, "known_answers.npz"), **known_answers(), **triangulation_known_answer())
         print("known_answers written")
 
 

@@ -314,6 +314,226 @@ __global__ __launch_bounds__(256) void k_cost(DeviceProblem d,
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_triangulate: multi-view triangulation of every landmark track from known poses -- the step on the
+// input side of the path.  One lane per landmark (the eigen-solve dominates: spreading
+// a track over G lanes repeats it G times and was 2-4x slower).
+//   1. linear (DLT) estimate, the algorithm of cv2.triangulatePoints that the reference calls for two
+//      views (visual_odometry.py:546-556), for any number of views: rows u P_2 - P_0 and v P_2 - P_1 of
+//      every view (P = K [R^T | -R^T c]) are accumulated into the 4x4 matrix A^T A, whose eigenvector of
+//      the smallest eigenvalue (Rayleigh-quotient iteration in registers, cyclic Jacobi as the fallback) is
+//      the homogeneous point.  Distorted pixels
+//      are undistorted first (fixed-point iteration on the radial factor).
+//   2. optional Gauss-Newton refinement of the reprojection error with the full camera model
+//      (initialization.py:96-143 sketches it with finite differences; analytic 2x3 blocks here): at most
+//      `refine_iters` steps, stops when |delta| < 1e-6.
+//   3. mean reprojection distance over the views ((e1 + e2) / 2 of visual_odometry.py:565-568) and a
+//      validity flag: finite, and deeper than min_depth in every view (initialization.py:148-155).
+// Algorithmic bytes: 20 B/obs (camera index + pixel) + 33 B/landmark written, poses from cache;
+// refinement re-reads the observations from L2.
+// One Jacobi rotation annihilating M[p][q] of the packed symmetric 4x4 matrix (p < q, compile-time).
+__host__ __device__ constexpr int sym4_index(int i, int j) {
+  return i <= j ? 4 * i - i * (i - 1) / 2 + (j - i) : 4 * j - j * (j - 1) / 2 + (i - j);
+}
+__device__ __forceinline__ void jacobi_rotate4(double M[10], double V[16], int p, int q) {
+  const double apq = M[sym4_index(p, q)];
+  if (apq == 0.0) return;
+  const double app = M[sym4_index(p, p)], aqq = M[sym4_index(q, q)];
+  const double theta = (aqq - app) / (2.0 * apq);
+  const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+  const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+  M[sym4_index(p, p)] = app - t * apq;
+  M[sym4_index(q, q)] = aqq + t * apq;
+  M[sym4_index(p, q)] = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (r != p && r != q) {
+      const double arp = M[sym4_index(r, p)], arq = M[sym4_index(r, q)];
+      M[sym4_index(r, p)] = c * arp - s * arq;
+      M[sym4_index(r, q)] = s * arp + c * arq;
+    }
+    const double vrp = V[4 * r + p], vrq = V[4 * r + q];
+    V[4 * r + p] = c * vrp - s * vrq;
+    V[4 * r + q] = s * vrp + c * vrq;
+  }
+}
+
+// Eigenvector of the smallest eigenvalue of the packed symmetric PSD 4x4 matrix M (sym4_index order), for a
+// point at finite distance.  Start: the inhomogeneous solution (w = 1) of the same rows; then Rayleigh-quotient
+// iteration (cubic convergence: three steps) with an LDL^T factorisation of M - mu I without pivoting: its
+// leading 3x3 block stays positive definite for a finite point (interlacing), only the last pivot is ~0.  The
+// number of negative pivots counts the eigenvalues below mu: more than one, or a residual that is not small,
+// means the iteration went elsewhere (degenerate geometry) and the cyclic Jacobi solver takes over.
+__device__ __forceinline__ bool smallest_eigvec4_rqi(const double M[10], double x[4]) {
+  const double v6[6] = {M[0], M[1], M[2], M[4], M[5], M[7]};
+  double inv[6];
+  damped_inv3(v6, 0.0, 0.0, inv);
+  const double rhs[3] = {-M[3], -M[6], -M[8]};
+  sym3_mul(inv, rhs, x);
+  x[3] = 1.0;
+  const double trace = M[0] + M[4] + M[7] + M[9];
+  const double tiny = 1e-300 + 1e-30 * trace;
+  bool ok = true;
+  double mu = 0.0;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    double y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      y[i] = 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) y[i] += M[sym4_index(i, c)] * x[c];
+    }
+    const double xx = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+    mu = (x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3]) / xx;
+    if (it == 3) {  // verdict: |M x - mu x| small against |M| |x|
+      double res = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) res += (y[i] - mu * x[i]) * (y[i] - mu * x[i]);
+      ok = ok && res <= 1e-22 * trace * trace * xx;
+      break;
+    }
+    // LDL^T of M - mu I (unit lower L, diagonal D)
+    double L10, L20, L30, L21, L31, L32, D0, D1, D2, D3;
+    D0 = M[0] - mu;
+    const double i0 = 1.0 / D0;
+    L10 = M[1] * i0; L20 = M[2] * i0; L30 = M[3] * i0;
+    D1 = (M[4] - mu) - L10 * M[1];
+    const double i1 = 1.0 / D1;
+    const double t21 = M[5] - L20 * M[1], t31 = M[6] - L30 * M[1];
+    L21 = t21 * i1; L31 = t31 * i1;
+    D2 = (M[7] - mu) - L20 * M[2] - L21 * t21;
+    const double i2 = 1.0 / D2;
+    const double t32 = M[8] - L30 * M[2] - L31 * t21;
+    L32 = t32 * i2;
+    D3 = (M[9] - mu) - L30 * M[3] - L31 * t31 - L32 * t32;
+    ok = ok && D0 > 0.0 && D1 > 0.0 && D2 > 0.0;  // exactly the smallest eigenvalue may lie below mu
+    if (fabs(D3) < tiny) D3 = tiny;
+    // solve (M - mu I) z = x
+    double z0 = x[0], z1 = x[1] - L10 * z0, z2 = x[2] - L20 * z0 - L21 * z1, z3 = x[3] - L30 * z0 - L31 * z1 - L32 * z2;
+    z0 *= i0; z1 *= i1; z2 *= i2; z3 /= D3;
+    z2 -= L32 * z3;
+    z1 -= L21 * z2 + L31 * z3;
+    z0 -= L10 * z1 + L20 * z2 + L30 * z3;
+    const double nz = 1.0 / sqrt(z0 * z0 + z1 * z1 + z2 * z2 + z3 * z3);
+    x[0] = z0 * nz; x[1] = z1 * nz; x[2] = z2 * nz; x[3] = z3 * nz;
+    ok = ok && isfinite(nz);
+  }
+  return ok && x[3] != 0.0;
+}
+
+__device__ __noinline__ void smallest_eigvec4_jacobi(const double M_in[10], double x[4]) {
+  double M[10], V[16];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) M[i] = M_in[i];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) V[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    const double off = M[1] * M[1] + M[2] * M[2] + M[3] * M[3] + M[5] * M[5] + M[6] * M[6] + M[8] * M[8];
+    const double dg = M[0] * M[0] + M[4] * M[4] + M[7] * M[7] + M[9] * M[9];
+    if (off <= 1e-32 * dg) break;
+    jacobi_rotate4(M, V, 0, 1); jacobi_rotate4(M, V, 0, 2); jacobi_rotate4(M, V, 0, 3);
+    jacobi_rotate4(M, V, 1, 2); jacobi_rotate4(M, V, 1, 3); jacobi_rotate4(M, V, 2, 3);
+  }
+  const double ev[4] = {M[0], M[4], M[7], M[9]};
+  int m = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i) m = ev[i] < ev[m] ? i : m;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[i] = m == 0 ? V[4 * i] : m == 1 ? V[4 * i + 1] : m == 2 ? V[4 * i + 2] : V[4 * i + 3];
+}
+
+__global__ __launch_bounds__(64) void k_triangulate(DeviceProblem d, const double* __restrict__ poses, int refine_iters,
+                                                    double min_depth, int force_jacobi, double* __restrict__ pts_out,
+                                                    double* __restrict__ err_out, unsigned char* __restrict__ valid_out) {
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= d.L_obs) return;
+  const int kb = d.lm_ptr[j], ke = d.lm_ptr[j + 1];
+  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  if (ke - kb < 2) {
+    err_out[j] = nan;
+    valid_out[j] = 0;
+    return;
+  }
+  const Intrinsics K = d.K;
+  // A^T A, packed upper triangle: 00 01 02 03 11 12 13 22 23 33
+  double M[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) M[i] = 0.0;
+  for (int k = kb; k < ke; ++k) {
+    const double* pose = poses + 7 * d.o_cam[k];
+    double R[9];
+    quat_to_R(pose + 3, R);
+    double u = d.o_u[k], v = d.o_v[k];
+    if (K.has_dist) {  // pixel of the undistorted ray
+      const double xd = (u - K.cx) / K.fx, yd = (v - K.cy) / K.fy;
+      double xn = xd, yn = yd;
+      for (int it = 0; it < 20; ++it) {
+        const double r2 = xn * xn + yn * yn;
+        const double f = 1.0 + K.k1 * r2 + K.k2 * r2 * r2 + K.k3 * r2 * r2 * r2;
+        xn = xd / f;
+        yn = yd / f;
+      }
+      u = K.fx * xn + K.cx;
+      v = K.fy * yn + K.cy;
+    }
+    // rows of [R^T | -R^T c]: row i = (R[0][i], R[1][i], R[2][i], -R[:, i] . c)
+    double E[3][4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      E[i][0] = R[i]; E[i][1] = R[3 + i]; E[i][2] = R[6 + i];
+      E[i][3] = -(R[i] * pose[0] + R[3 + i] * pose[1] + R[6 + i] * pose[2]);
+    }
+    double a[4], b[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double p0 = K.fx * E[0][c] + K.cx * E[2][c], p1 = K.fy * E[1][c] + K.cy * E[2][c], p2 = E[2][c];
+      a[c] = u * p2 - p0;
+      b[c] = v * p2 - p1;
+    }
+    int e = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = r; c < 4; ++c) M[e++] += a[r] * a[c] + b[r] * b[c];
+  }
+  double hx[4];
+  if (force_jacobi || !smallest_eigvec4_rqi(M, hx)) smallest_eigvec4_jacobi(M, hx);
+  double X[3] = {hx[0] / hx[3], hx[1] / hx[3], hx[2] / hx[3]};
+
+  for (int it = 0; it < refine_iters; ++it) {
+    double Hh[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    for (int k = kb; k < ke; ++k) {
+      double r[2], Jc[12], Jp[6], zc;
+      linearize_obs(K, poses + 7 * d.o_cam[k], X, d.o_u[k], d.o_v[k], r, Jc, Jp, zc);
+      Hh[0] += Jp[0] * Jp[0] + Jp[3] * Jp[3]; Hh[1] += Jp[0] * Jp[1] + Jp[3] * Jp[4]; Hh[2] += Jp[0] * Jp[2] + Jp[3] * Jp[5];
+      Hh[3] += Jp[1] * Jp[1] + Jp[4] * Jp[4]; Hh[4] += Jp[1] * Jp[2] + Jp[4] * Jp[5]; Hh[5] += Jp[2] * Jp[2] + Jp[5] * Jp[5];
+      g[0] += Jp[0] * r[0] + Jp[3] * r[1]; g[1] += Jp[1] * r[0] + Jp[4] * r[1]; g[2] += Jp[2] * r[0] + Jp[5] * r[1];
+    }
+    double Hi[6], dx[3];
+    damped_inv3(Hh, 0.0, 0.0, Hi);
+    sym3_mul(Hi, g, dx);
+    X[0] -= dx[0]; X[1] -= dx[1]; X[2] -= dx[2];
+    if (dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2] < 1e-12) break;
+  }
+
+  double err = 0.0;
+  bool ok = isfinite(X[0]) && isfinite(X[1]) && isfinite(X[2]);
+  for (int k = kb; k < ke; ++k) {
+    const double* pose = poses + 7 * d.o_cam[k];
+    double R[9], Xc[3], r0, r1;
+    quat_to_R(pose + 3, R);
+    to_camera(R, pose, X, Xc);
+    reproject(K, Xc, d.o_u[k], d.o_v[k], r0, r1);
+    err += sqrt(r0 * r0 + r1 * r1);
+    ok = ok && Xc[2] > min_depth;
+  }
+  err /= (double)(ke - kb);
+  pts_out[3 * j] = X[0]; pts_out[3 * j + 1] = X[1]; pts_out[3 * j + 2] = X[2];
+  err_out[j] = err;
+  valid_out[j] = (ok && isfinite(err)) ? 1 : 0;
+}
+
 // Export kernel for ba_jacobian_blocks (caller's observation order).
 __global__ __launch_bounds__(256) void k_export_jac(DeviceProblem d,
                                                     const double* __restrict__ poses, const double* __restrict__ pts,

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <limits>
 #include <vector>
 
 #include <dlfcn.h>
@@ -1233,6 +1234,79 @@ int ba_evaluate(ba_handle* h, const double* poses, const double* points, double*
   if (n_behind) *n_behind = (int32_t)h->scal_host[SC_NBEHIND_T];
   if (h->scal_host[SC_ZEROZ] > 0.0)
     return fail(h, BA_ERR_NUMERICAL, "cannot project points with zero Z coordinates (division by zero)");
+  return BA_OK;
+}
+
+int ba_triangulate(ba_handle* h, const double* poses, int32_t refine_iters, double min_depth, double* points,
+                   double* reproj_err, uint8_t* valid) {
+  if (!h) return BA_ERR_INVALID;
+  if (!h->has_problem) return fail(h, BA_ERR_STATE, "triangulate before set_problem");
+  if (!poses || !points) return fail(h, BA_ERR_INVALID, "null poses/points");
+  if (refine_iters < 0 || !std::isfinite(min_depth)) return fail(h, BA_ERR_INVALID, "refine_iters < 0 or min_depth not finite");
+  HIP_TRY(h, hipSetDevice(h->device));
+  // poses as in stage_state (every pose is data here: normalise all quaternions)
+  double* sp = h->stage;
+  for (int c = 0; c < h->C; ++c) {
+    const double* p = poses + 7 * c;
+    for (int i = 0; i < 7; ++i)
+      if (!std::isfinite(p[i])) return fail(h, BA_ERR_INVALID, "pose %d has a non-finite entry", c);
+    const double nq = std::sqrt(p[3] * p[3] + p[4] * p[4] + p[5] * p[5] + p[6] * p[6]);
+    if (nq == 0.0) return fail(h, BA_ERR_INVALID, "pose %d has a zero quaternion", c);
+    for (int i = 0; i < 3; ++i) sp[7 * c + i] = p[i];
+    for (int i = 3; i < 7; ++i) sp[7 * c + i] = p[i] / nq;
+  }
+  h->has_estimate = false;  // the trial buffers are used as scratch
+  double* d_poses = h->d.poses_buf[1];
+  double* d_pts = h->d.pts_buf[1];
+  const int Lo = h->L_obs;
+  double* d_err = nullptr;
+  unsigned char* d_valid = nullptr;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  HIP_TRY(h, hipMemcpyAsync(d_poses, sp, (size_t)h->C * 7 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (Lo > 0) {
+    HIP_TRY(h, hipMalloc((void**)&d_err, (size_t)Lo * sizeof(double)));
+    if (hipMalloc((void**)&d_valid, (size_t)Lo) != hipSuccess) {
+      (void)hipFree(d_err);
+      return fail(h, BA_ERR_NOMEM, "triangulate: device allocation failed");
+    }
+    const int grid = grid_for(Lo, 64);
+    const int force_jacobi = env_int("BA_TRI_JACOBI", 0);
+    if (h->opt.profile_kernels) {  // outside a solve: the span is read right here (class "other")
+      ev_a = next_event(h); ev_b = next_event(h);
+      hipExtLaunchKernelGGL(k_triangulate, dim3(grid), dim3(64), 0, h->stream, ev_a, ev_b, 0, h->d, (const double*)d_poses,
+                            (int)refine_iters, min_depth, force_jacobi, d_pts, d_err, d_valid);
+    } else {
+      hipLaunchKernelGGL(k_triangulate, dim3(grid), dim3(64), 0, h->stream, h->d, (const double*)d_poses,
+                         (int)refine_iters, min_depth, force_jacobi, d_pts, d_err, d_valid);
+    }
+  }
+  std::vector<double> err((size_t)Lo);
+  std::vector<unsigned char> ok((size_t)Lo);
+  double* sx = h->stage + (size_t)h->C * 7;
+  hipError_t e = hipSuccess;
+  if (Lo > 0) {
+    e = hipMemcpyAsync(sx, d_pts, (size_t)Lo * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(err.data(), d_err, (size_t)Lo * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ok.data(), d_valid, (size_t)Lo, hipMemcpyDeviceToHost, h->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (ev_a) {
+    float ms = 0.f;
+    if (e == hipSuccess && hipEventElapsedTime(&ms, ev_a, ev_b) == hipSuccess) { h->ktime_ms[KT_OTHER] += ms; h->kcount[KT_OTHER] += 1; }
+    h->ev_used = 0;
+  }
+  if (d_err) (void)hipFree(d_err);
+  if (d_valid) (void)hipFree(d_valid);
+  if (e != hipSuccess) return fail(h, BA_ERR_DEVICE, "triangulate: %s", hipGetErrorString(e));
+  const double nan = std::numeric_limits<double>::quiet_NaN();
+  if (reproj_err) for (int j = 0; j < h->L; ++j) reproj_err[j] = nan;
+  if (valid) std::memset(valid, 0, (size_t)h->L);
+  for (int j = 0; j < Lo; ++j) {
+    const size_t u = (size_t)h->lm_internal_to_user[j];
+    if (reproj_err) reproj_err[u] = err[j];
+    if (valid) valid[u] = ok[j];
+    if (ok[j]) std::memcpy(points + 3 * u, sx + 3 * (size_t)j, 3 * sizeof(double));  // others stay untouched
+  }
   return BA_OK;
 }
 

@@ -72,6 +72,7 @@ _SIGNATURES = {
     "ba_download_estimate": (C.c_int, [_P, _D, _D]),
     "ba_solve_batched": (C.c_int, [_P, C.c_int32, _I, _I, _I, _I, _I, _D, _D, _D, _D, _D, _D, C.POINTER(BaReport)]),
     "ba_evaluate": (C.c_int, [_P, _D, _D, _D, _D, _I]),
+    "ba_triangulate": (C.c_int, [_P, _D, C.c_int32, C.c_double, _D, _D, C.POINTER(C.c_uint8)]),
     "ba_jacobian_blocks": (C.c_int, [_P, _D, _D, _D, _D]),
     "ba_debug_linearization": (C.c_int, [_P, _D, _D, C.c_double] + [_D] * 9),
     "ba_schur_block_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),
@@ -263,6 +264,18 @@ class Solver:
         self._check(self._lib.ba_evaluate(self._h, _dptr(poses), _dptr(points), _dptr(res), C.byref(cost),
                                           C.byref(nb)))
         return res, cost.value, nb.value
+
+    def triangulate(self, poses, points=None, refine_iters: int = 0, min_depth: float = 0.0):
+        """Triangulate every landmark of the problem from the given poses (ba_triangulate).  Returns
+        (points L x 3, reprojection error L, valid L); rows of `points` (zeros if not given) that are not
+        valid are left as passed."""
+        poses = _f64(poses, (self.C, 7)).copy()
+        points = np.zeros((self.L, 3)) if points is None else _f64(points, (self.L, 3)).copy()
+        err = np.empty(self.L)
+        valid = np.zeros(self.L, dtype=np.uint8)
+        self._check(self._lib.ba_triangulate(self._h, _dptr(poses), int(refine_iters), float(min_depth), _dptr(points),
+                                             _dptr(err), valid.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return points, err, valid.astype(bool)
 
     def jacobian_blocks(self, poses, points):
         poses, points = self._state(poses, points)
