@@ -274,16 +274,28 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
   return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
+// Sum / max over aligned groups of WIDTH lanes, returned to every lane of the group (the same bits in all
+// of them: every step adds the two partial sums of a pair).  Within a 16-lane row the steps are DPP moves
+// (a few cycles each); ds_bpermute shuffles (~100 cycles each, measured) only cross rows.
 template <int WIDTH>
 __device__ __forceinline__ double group_sum(double v) {
-#pragma unroll
-  for (int m = WIDTH / 2; m > 0; m >>= 1) v += __shfl_xor(v, m, WIDTH);
+  static_assert(WIDTH == 2 || WIDTH == 4 || WIDTH == 8 || WIDTH == 16 || WIDTH == 32 || WIDTH == 64, "group width");
+  v += dpp_move_f64<0xB1>(v);                             // quad_perm [1,0,3,2]
+  if constexpr (WIDTH >= 4) v += dpp_move_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  if constexpr (WIDTH >= 8) v += dpp_move_f64<0x141>(v);  // row_half_mirror
+  if constexpr (WIDTH >= 16) v += dpp_move_f64<0x140>(v); // row_mirror
+  if constexpr (WIDTH >= 32) v += __shfl_xor(v, 16, 64);
+  if constexpr (WIDTH >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
 template <int WIDTH>
 __device__ __forceinline__ double group_max(double v) {
-#pragma unroll
-  for (int m = WIDTH / 2; m > 0; m >>= 1) v = fmax(v, __shfl_xor(v, m, WIDTH));
+  v = fmax(v, dpp_move_f64<0xB1>(v));
+  if constexpr (WIDTH >= 4) v = fmax(v, dpp_move_f64<0x4E>(v));
+  if constexpr (WIDTH >= 8) v = fmax(v, dpp_move_f64<0x141>(v));
+  if constexpr (WIDTH >= 16) v = fmax(v, dpp_move_f64<0x140>(v));
+  if constexpr (WIDTH >= 32) v = fmax(v, __shfl_xor(v, 16, 64));
+  if constexpr (WIDTH >= 64) v = fmax(v, __shfl_xor(v, 32, 64));
   return v;
 }
 
