@@ -86,6 +86,9 @@ struct DeviceProblem {
   const int* comp_slot_ptr;  // [n_comp + 1] into comp_slots
   const int* comp_slots;     // [nu] upper S slots grouped by component
   int n_comp;
+  const int* lin_lm;     // [n_lin_chunks + 1] first landmark of each k_linearize_flat chunk
+  const int* lin_k;      // [n_lin_chunks + 1] first observation of each chunk
+  int n_lin_chunks;      // 0: k_linearize<G> is used
   const int* sch_lm;     // [n_chunks + 1] first landmark of each k_schur_staged chunk
   const int* sch_k;      // [n_chunks + 1] first observation of each chunk (= lm_ptr[sch_lm[.]])
   const unsigned* sch_flush;  // [n_chunks] bit s: the wave writes its accumulators out before step s of the chunk
@@ -262,6 +265,162 @@ __global__ __launch_bounds__(64, ROBUST ? 1 : LIN_WAVES) void k_linearize(Device
   gmax = group_max<64>(gmax);
   const double bb = group_sum<64>((double)nbehind), bz = group_sum<64>((double)nzero);
   if (lane == 0) {
+    double* sc = SCAL_MINE(d);
+    atomic_add_f64(&sc[SC_COST], cost);
+    if (bb != 0.0) atomic_add_f64(&sc[SC_NBEHIND], bb);
+    if (bz != 0.0) atomic_add_f64(&sc[SC_ZEROZ], bz);
+    atomic_max_nonneg(&sc[SC_GINF], gmax);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_linearize_flat: the same linearisation with one LANE PER OBSERVATION, for problems with few cameras
+// (<= LINF_MAXC, so U / gc of all of them fit in LDS) and tracks of at most LINF_MAXLM observations.
+// k_linearize<G> keeps a group of G lanes on one track: with 10 observations per track 40 of 64 lanes work,
+// and its instruction stream per track is dominated by bookkeeping (measured: 826 VALU instructions per
+// wave-iteration of 40 observations, two waves per SIMD more than half VALU-busy).  Here the host cuts the
+// landmark list into chunks of whole tracks with <= 64 observations; a wave takes a chunk per iteration:
+//   lane t loads observation t (coalesced), its point and pose (gathers from cache), linearises, stores its
+//   W block (18 coalesced stores), parks its 2x3-block products in LDS; lane l < landmarks-in-chunk then sums
+//   the rows of track l in track order (deterministic) and stores V, gp.  U / gc go into a per-workgroup LDS
+//   copy by LDS atomics, and the workgroup adds that copy to its global slab once.
+constexpr int LINF_MAXC = 64;     // cameras: the per-workgroup copy of U | gc costs C * 27 LDS words to clear and scan (at 150 cameras
+                                  // the kernel is slower than k_linearize<G>: 45 vs 32 us on 480 k observations)
+constexpr int LINF_MAXLM = 32;    // landmarks per chunk == longest track
+constexpr int LINF_VSTRIDE = 11;  // 9 values per observation + pad (odd: conflict-free column access)
+constexpr int LINF_WAVES = 4;     // waves per workgroup
+
+template <bool ROBUST>
+__global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_flat(DeviceProblem d, const double* __restrict__ poses,
+                                                                       const double* __restrict__ pts) {
+  // One chunk per wave and no loop: every load of the wave is issued in two dependent rounds (chunk bounds
+  // by scalar loads; then observation records, track bounds and the chunk's points, all independent), poses
+  // come from an LDS copy.  (A software-pipelined loop over several chunks was slower: loads and stores
+  // retire in order through one counter, and the compiler waits for everything outstanding, the previous
+  // chunk's stores included, before each dependent round.)
+  extern __shared__ double lds[];
+  double* sU = lds;                                                   // [C][27]
+  double* sPose = sU + d.C * 27;                                      // [C][7]
+  double* sVg = sPose + d.C * 7;                                      // [LINF_WAVES][64][LINF_VSTRIDE]
+  double* sP = sVg + LINF_WAVES * 64 * LINF_VSTRIDE;                  // [LINF_WAVES][LINF_MAXLM][3]
+  if (poses == nullptr) {  // solver mode
+    const LmCtrl* c = d.ctrl;
+    if (c->done || !c->need_lin) return;
+    poses = d.poses_buf[c->sel];
+    pts = d.pts_buf[c->sel];
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = __builtin_amdgcn_readfirstlane(blockIdx.x * LINF_WAVES + wave);
+  const bool have = c < d.n_lin_chunks;
+  // round 1: chunk bounds (scalar), poses -> LDS
+  int kb = 0, ke = 0, jb = 0, je = 0;
+  if (have) { jb = d.lin_lm[c]; je = d.lin_lm[c + 1]; kb = d.lin_k[c]; ke = d.lin_k[c + 1]; }
+  for (int i = tid; i < d.C * 7; i += 64 * LINF_WAVES) sPose[i] = poses[i];
+  for (int i = tid; i < d.C * 27; i += 64 * LINF_WAVES) sU[i] = 0.0;
+  // round 2: observation record, track bounds and points of the chunk
+  const int k = kb + lane;
+  const bool act = k < ke;
+  int cam = -1, fr = -1, lm = jb, tb = 0, te = 0;
+  double u = 0.0, v = 0.0, Pl[3] = {0.0, 0.0, 1.0};
+  if (act) { cam = d.o_cam[k]; fr = d.o_free[k]; lm = d.o_lm[k]; u = d.o_u[k]; v = d.o_v[k]; }
+  const bool lm_lane = lane < je - jb;
+  if (lm_lane) {
+    tb = d.lm_ptr[jb + lane] - kb; te = d.lm_ptr[jb + lane + 1] - kb;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Pl[i] = pts[3 * (long)(jb + lane) + i];
+  }
+  double* myP = sP + wave * LINF_MAXLM * 3;
+  double* myV = sVg + (wave * 64) * LINF_VSTRIDE;
+  if (lm_lane) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) myP[3 * lane + i] = Pl[i];
+  }
+  __syncthreads();  // sPose, sU, myP
+  const bool is_free = act && fr >= 0;
+  double cost = 0.0, gmax = 0.0;
+  int nbehind = 0, nzero = 0;
+  double vg[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) vg[i] = 0.0;
+  if (act) {
+    const double P[3] = {myP[3 * (lm - jb)], myP[3 * (lm - jb) + 1], myP[3 * (lm - jb) + 2]};
+    double pose[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) pose[i] = sPose[7 * cam + i];
+    double r[2], Jc[12], Jp[6], zc;
+    linearize_obs(d.K, pose, P, u, v, r, Jc, Jp, zc);
+    nbehind += (zc <= 0.0);
+    nzero += (zc == 0.0);
+    if (!ROBUST) {
+      cost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        double sc;
+        cost += robust_scale(d.loss, r[i], sc);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Jc[6 * i + q] *= sc;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) Jp[3 * i + q] *= sc;
+      }
+    }
+    vg[0] = Jp[0] * Jp[0] + Jp[3] * Jp[3];
+    vg[1] = Jp[0] * Jp[1] + Jp[3] * Jp[4];
+    vg[2] = Jp[0] * Jp[2] + Jp[3] * Jp[5];
+    vg[3] = Jp[1] * Jp[1] + Jp[4] * Jp[4];
+    vg[4] = Jp[1] * Jp[2] + Jp[4] * Jp[5];
+    vg[5] = Jp[2] * Jp[2] + Jp[5] * Jp[5];
+    vg[6] = Jp[0] * r[0] + Jp[3] * r[1];
+    vg[7] = Jp[1] * r[0] + Jp[4] * r[1];
+    vg[8] = Jp[2] * r[0] + Jp[5] * r[1];
+    if (!is_free) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
+    }
+    double* __restrict__ Wk = d.W + k;
+    const long n = d.n;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) Wk[(long)(3 * i + q) * n] = Jc[i] * Jp[q] + Jc[6 + i] * Jp[3 + q];
+    if (is_free) {  // U / gc of this observation into the workgroup's copy
+      double* Uc = sU + cam * 27;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int q = i; q < 6; ++q) atomic_add_f64(&Uc[sym6_index(i, q)], Jc[i] * Jc[q] + Jc[6 + i] * Jc[6 + q]);
+        atomic_add_f64(&Uc[21 + i], Jc[i] * r[0] + Jc[6 + i] * r[1]);
+      }
+    }
+  }
+  // V, gp of the chunk's landmarks: rows parked per observation, summed per track in track order
+#pragma unroll
+  for (int i = 0; i < 9; ++i) myV[lane * LINF_VSTRIDE + i] = vg[i];
+  __syncthreads();  // myV rows; all U / gc contributions of the workgroup
+  if (lm_lane) {
+    const int jl = jb + lane;
+    double s9[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s9[i] = 0.0;
+    for (int t = tb; t < te; ++t) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) s9[i] += myV[t * LINF_VSTRIDE + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d.V[(long)i * d.L + jl] = s9[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d.gp[(long)i * d.L + jl] = s9[6 + i];
+    gmax = fmax(fabs(s9[6]), fmax(fabs(s9[7]), fabs(s9[8])));
+  }
+  double* __restrict__ Uslab = d.Ugc_slab + (long)(blockIdx.x % d.nslab_u) * d.C * 27;
+  for (int i = tid; i < d.C * 27; i += 64 * LINF_WAVES) {
+    const double x = sU[i];
+    if (x != 0.0) atomic_add_f64(Uslab + i, x);
+  }
+  cost = wave_sum_dpp(cost);
+  gmax = group_max<64>(gmax);
+  const double bb = wave_sum_dpp((double)nbehind), bz = wave_sum_dpp((double)nzero);
+  if (lane == 0 && have) {
     double* sc = SCAL_MINE(d);
     atomic_add_f64(&sc[SC_COST], cost);
     if (bb != 0.0) atomic_add_f64(&sc[SC_NBEHIND], bb);

@@ -79,6 +79,7 @@ struct ba_handle {
   std::vector<int> urow_ptr, ucol;
   std::vector<uint8_t> fixed;
   int g_lin = 16, g_schur = 64, lpg_lin = 1, lpg_schur = 1, lpg_back = 1;
+  int lin_cpw = 0;  // 1: k_linearize_flat (one chunk of whole tracks per wave) replaces k_linearize<G>
   int schur_cpb = 0;  // > 0: k_schur_staged with this many chunks per block
   bool small_solve = false;
   bool comp_solve = false;  // dense Cholesky per connected component of the camera graph
@@ -239,9 +240,22 @@ void launch_timed(ba_handle* h, int cls, void (*kern)(KArgs...), int grid, int b
   launch_timed_lds(h, cls, kern, grid, block, 0, args...);
 }
 
+inline size_t linf_lds_bytes(int C) {
+  return ((size_t)C * 34 + (size_t)LINF_WAVES * (64 * LINF_VSTRIDE + LINF_MAXLM * 3)) * sizeof(double);
+}
+
 // poses / pts == nullptr: solver mode (state and run/skip decision come from the device-side LM control)
 void launch_linearize(ba_handle* h, const double* poses, const double* pts) {
   const DeviceProblem& d = h->d;
+  if (h->lin_cpw > 0) {
+    const int grid = grid_for(d.n_lin_chunks, LINF_WAVES);
+    const size_t lds = linf_lds_bytes(d.C);
+    if (d.loss.kind == LOSS_LINEAR)
+      launch_timed_lds(h, KT_LIN, k_linearize_flat<false>, grid, 64 * LINF_WAVES, lds, d, poses, pts);
+    else
+      launch_timed_lds(h, KT_LIN, k_linearize_flat<true>, grid, 64 * LINF_WAVES, lds, d, poses, pts);
+    return;
+  }
   const int G = h->g_lin, lpg = h->lpg_lin;
   const int grid = grid_for(d.L_obs, (64 / G) * lpg);
   if (d.loss.kind == LOSS_LINEAR) {
@@ -885,6 +899,26 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
                            (int)std::max<long>(1, (L_obs + waves_schur * gpw_schur - 1) / (waves_schur * gpw_schur)));
     h->lpg_back = env_int("BA_LPG_BACK", 1);
   }
+  // ---- k_linearize_flat chunks: whole tracks, <= 64 observations and <= LINF_MAXLM landmarks each
+  std::vector<int> lin_lm(1, 0), lin_k(1, 0);
+  h->lin_cpw = 0;
+  {
+    int maxlen = 0;
+    for (int j = 0; j < L_obs; ++j) maxlen = std::max(maxlen, lm_ptr[j + 1] - lm_ptr[j]);
+    if (env_int("BA_LIN_FLAT", 1) != 0 && C <= LINF_MAXC && maxlen <= LINF_MAXLM && L_obs > 0) {
+      lin_lm.clear(); lin_k.clear();
+      for (int j = 0; j < L_obs;) {
+        lin_lm.push_back(j);
+        lin_k.push_back(lm_ptr[j]);
+        int j1 = j + 1;
+        while (j1 < L_obs && j1 - j < LINF_MAXLM && lm_ptr[j1 + 1] - lm_ptr[j] <= 64) ++j1;
+        j = j1;
+      }
+      lin_lm.push_back(L_obs);
+      lin_k.push_back(lm_ptr[L_obs]);
+      h->lin_cpw = 1;
+    }
+  }
   // ---- k_schur_staged tables: chunks (consecutive landmarks, <= SCH_CAP observations, <= SCH_MAXLM
   // landmarks), the steps at which a wave must write its accumulators out (some lane's camera pair
   // changes), the contribution rows those write-outs fill, and the inverted index S block -> rows.
@@ -1071,6 +1105,12 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
                    (intr[4] != 0.0 || intr[5] != 0.0 || intr[6] != 0.0) ? 1 : 0};
   d.loss = RobustLoss{h->opt.loss, h->opt.f_scale * h->opt.f_scale, 1.0 / (h->opt.f_scale * h->opt.f_scale)};
   d.nu = nu; d.nl = nl; d.nb = nb;
+  d.n_lin_chunks = h->lin_cpw > 0 ? (int)lin_lm.size() - 1 : 0;
+  if (h->lin_cpw > 0) {
+    const int lds = (int)linf_lds_bytes(C);
+    HIP_TRY(h, hipFuncSetAttribute((const void*)k_linearize_flat<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(h, hipFuncSetAttribute((const void*)k_linearize_flat<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  }
   int rc;
   if ((rc = dev_upload(h, &d.o_cam, o_cam)) || (rc = dev_upload(h, &d.o_u, o_u)) || (rc = dev_upload(h, &d.o_v, o_v)) ||
       (rc = dev_upload(h, &d.o_src, o_src)) || (rc = dev_upload(h, &d.o_lm, o_lm)) ||
@@ -1085,6 +1125,7 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
       (rc = dev_upload(h, &d.comp_ptr, comp_ptr)) || (rc = dev_upload(h, &d.comp_cams, comp_cams)) ||
       (rc = dev_upload(h, &d.comp_local, comp_local)) || (rc = dev_upload(h, &d.comp_slot_ptr, comp_slot_ptr)) ||
       (rc = dev_upload(h, &d.comp_slots, comp_slots)) ||
+      (rc = dev_upload(h, &d.lin_lm, lin_lm)) || (rc = dev_upload(h, &d.lin_k, lin_k)) ||
       (rc = dev_upload(h, &d.sch_lm, sch_lm)) || (rc = dev_upload(h, &d.sch_k, sch_k)) ||
       (rc = dev_upload(h, &d.sch_flush, sch_flush)) || (rc = dev_upload(h, &d.sch_blk_row, sch_blk_row)) ||
       (rc = dev_upload(h, &d.ctr_ptr, ctr_ptr)) || (rc = dev_upload(h, &d.ctr_row, ctr_row)) ||
