@@ -47,7 +47,13 @@ typedef enum {
  * least_squares call produces (scipy/optimize/_lsq/common.py:705-717): */
 typedef enum { BA_STOP_MAX_ITERS = 0, BA_STOP_GTOL = 1, BA_STOP_FTOL = 2, BA_STOP_XTOL = 3 } ba_stop;
 
-typedef enum { BA_SOLVER_AUTO = 0, BA_SOLVER_PCG = 1, BA_SOLVER_DENSE_CHOLESKY = 2 } ba_linear_solver;
+typedef enum {
+  BA_SOLVER_AUTO = 0,
+  BA_SOLVER_PCG = 1,
+  BA_SOLVER_DENSE_CHOLESKY = 2,
+  BA_SOLVER_BANDED_CHOLESKY = 3 /* block-banded (+ arrow) Cholesky: cameras that only share landmarks with their
+                                   neighbours along a trajectory, possibly closed into a loop */
+} ba_linear_solver;
 
 /* Robust loss, applied to every scalar residual with the semantics of the `loss=` / `f_scale=`
  * arguments of scipy.optimize.least_squares (scipy/optimize/_lsq/least_squares.py:186-236): the hook
@@ -235,6 +241,11 @@ int ba_set_kernel_timing(ba_handle* h, int32_t on);
  * path runs with single-rank collectives. */
 int ba_comm_unique_id(char* id128);
 int ba_comm_init(ba_handle* h, int32_t rank, int32_t world, const char* id128);
+
+/* Which solver ba_set_problem chose for the reduced camera system: 0 multi-kernel PCG, 1 one-workgroup PCG,
+ * 2 whole-GPU dense Cholesky, 3 banded + arrow Cholesky, 4 dense Cholesky per connected component (batched
+ * windows).  No reference counterpart. */
+int ba_reduced_solver(const ba_handle* h, int32_t* kind);
 
 /* Number of stored 6x6 blocks of the reduced camera system (upper triangle incl. diagonal). */
 int ba_schur_block_count(const ba_handle* h, int64_t* n_upper_blocks);

@@ -118,3 +118,56 @@ def test_batched_rejects_bad_input():
     with _native.Solver() as s:
         with pytest.raises(ValidationError):
             s.solve_batched([probs[0], bad], scs[0]["intr"])
+
+
+def _open_trajectory(C, L, d):
+    """Ring scene without the observations that wrap around: an open trajectory (ragged tracks at its end)."""
+    sc = scenes.ring_scene(C, L, d)
+    keep = sc["obs_cam"] >= (sc["obs_pt"] % C)
+    return dict(sc, obs_cam=sc["obs_cam"][keep], obs_pt=sc["obs_pt"][keep], obs_uv=sc["obs_uv"][keep])
+
+
+@pytest.mark.parametrize("make", [lambda: scenes.ring_scene(60, 1200, 5), lambda: _open_trajectory(60, 1200, 5)],
+                         ids=["closed_loop", "open_trajectory"])
+def test_banded_cholesky_step_matches_oracle(make):
+    """One LM step of the banded + arrow Cholesky (ba_banded.h) against a dense numpy solve of the oracle's
+    reduced system: 1e-9 relative (direct solver)."""
+    sc = make()
+    C, L = len(sc["poses_gt"]), len(sc["points_gt"])
+    poses, pts = sc["poses_guess"], sc["points_guess"]
+    lam = 1e-3
+    with _native.Solver(linear_solver=3) as s:
+        s.set_problem(C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+        assert s.reduced_solver() == "banded_cholesky"
+        out = s.debug_linearization(poses, pts, lam)
+    r, Jc, Jp = lm.linearize(poses, pts, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+    free = np.ones(C, bool)
+    free[0] = False
+    Jc = Jc * free[sc["obs_cam"]][:, None, None]
+    U, V, W, gc, gp, _ = lm.normal_blocks(r, Jc, Jp, sc["obs_cam"], sc["obs_pt"], C, L)
+    S, rhs, Vi = lm.schur_system(U, V, W, gc, gp, sc["obs_cam"], sc["obs_pt"], lam, free)
+    dc = np.linalg.solve(S, -rhs).reshape(C, 6) * free[:, None]
+    dp = lm.back_substitute(dc, Vi, W, gp, sc["obs_cam"], sc["obs_pt"], L)
+    np.testing.assert_allclose(out["dc"], dc, rtol=0, atol=1e-9 * np.abs(dc).max())
+    np.testing.assert_allclose(out["dp"], dp, rtol=0, atol=1e-9 * np.abs(dp).max())
+
+
+def test_banded_cholesky_is_chosen_and_converges_like_dense():
+    """AUTO takes the banded solver for a long trajectory; the solve follows the dense Cholesky's path."""
+    sc = scenes.ring_scene(300, 6000, 5)
+    reps = {}
+    for name, opt in (("auto", {}), ("dense", dict(linear_solver=2))):
+        with _native.Solver(**opt) as s:
+            s.set_problem(300, 6000, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+            reps[name] = (s.reduced_solver(), s.solve(sc["poses_guess"], sc["points_guess"])[2])
+    assert reps["auto"][0] == "banded_cholesky" and reps["dense"][0] == "dense_cholesky"
+    a, b = reps["auto"][1], reps["dense"][1]
+    assert a["iterations"] == b["iterations"] and a["status"] == b["status"]
+    assert abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"]
+
+
+def test_banded_cholesky_rejects_unstructured_problems():
+    sc = scenes.ring_scene(200, 4000, 5, visibility="random")
+    with _native.Solver(linear_solver=3) as s:
+        with pytest.raises(Exception):
+            s.set_problem(200, 4000, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])

@@ -4,6 +4,7 @@
 #include "../../include/ba_amd.h"
 #include "ba_kernels.h"
 #include "ba_dense.h"
+#include "ba_banded.h"
 
 #include <algorithm>
 #include <chrono>
@@ -85,6 +86,10 @@ struct ba_handle {
   bool comp_solve = false;  // dense Cholesky per connected component of the camera graph
   size_t comp_lds = 0;
   bool dense_solve = false;  // whole-GPU dense Cholesky of the reduced system (ba_dense.h)
+  bool banded_solve = false; // banded + arrow block Cholesky in one workgroup (ba_banded.h)
+  BandedShape bshape{};
+  double* banded_B = nullptr;
+  size_t banded_lds = 0;
   double* dense_A = nullptr;
   int dense_nt = 0;
   size_t small_lds = 0;
@@ -361,6 +366,18 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
     *pcg_iters = -1;
     return BA_OK;
   }
+  if (h->banded_solve) {
+    const LmCtrl* ctrl = mode ? d.ctrl : nullptr;
+    const BandedShape& sh = h->bshape;
+    HIP_TRY(h, hipMemsetAsync(h->banded_B, 0, (size_t)sh.Cf * sh.nrow * 36 * sizeof(double), h->stream));
+    launch_timed(h, KT_PCG, k_banded_assemble, grid_for((long)d.nu * 36 + 6L * d.Cf), 256, d, h->banded_B, sh, lam,
+                 o.min_diag, mode);
+    launch_timed_lds(h, KT_PCG, k_banded_factor, 1, BND_THREADS, h->banded_lds, h->banded_B, sh, ctrl, d.scal + SC_BADV);
+    launch_timed_lds(h, KT_PCG, k_banded_backsolve, 1, 64, (size_t)((sh.bw + 1 + std::max(sh.na, 1)) * 6 + 66) * sizeof(double),
+                     (const double*)h->banded_B, sh, ctrl, d.dc);
+    *pcg_iters = -1;
+    return BA_OK;
+  }
   if (h->dense_solve) {
     const LmCtrl* ctrl = mode ? d.ctrl : nullptr;
     const int nt = h->dense_nt;
@@ -501,7 +518,8 @@ int lm_solve(ba_handle* h, ba_report* rep) {
   HIP_TRY(h, hipMemcpyAsync(d.pts_buf[0], h->pts_init, pts_bytes, hipMemcpyDeviceToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(d.pts_buf[1], h->pts_init, pts_bytes, hipMemcpyDeviceToDevice, h->stream));
 
-  const int check_every = (h->small_solve || h->comp_solve || h->dense_solve) ? std::max(1, o.lm_check_every) : 1;
+  const int check_every =
+      (h->small_solve || h->comp_solve || h->dense_solve || h->banded_solve) ? std::max(1, o.lm_check_every) : 1;
   h->mirror->seq = 0;
   int enq = 0, rc;
   bool done = false;
@@ -691,6 +709,13 @@ int ba_comm_init(ba_handle* h, int32_t rank, int32_t world, const char* id128) {
   h->rank = rank;
   h->world = world;
   free_problem(h);  // a problem set before the communicator existed has a rank-local pattern
+  return BA_OK;
+}
+
+int ba_reduced_solver(const ba_handle* h, int32_t* kind) {
+  if (!h || !kind) return BA_ERR_INVALID;
+  if (!h->has_problem) return BA_ERR_STATE;
+  *kind = h->comp_solve ? 4 : h->banded_solve ? 3 : h->dense_solve ? 2 : h->small_solve ? 1 : 0;
   return BA_OK;
 }
 
@@ -1087,6 +1112,40 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
         return fail(h, BA_ERR_INVALID, "dense Cholesky is limited to %d free cameras (here: %d)", DENSE_MAX_CAMS, Cf);
       h->dense_solve = false;
     }
+    // banded + arrow shape of the pattern in the camera order: for every arrow size na, the half-bandwidth of the
+    // blocks that lie outside the last na rows; the cheapest window wins
+    h->banded_solve = false;
+    if (Cf > 0 && !h->comp_solve && env_int("BA_BANDED_SOLVE", 1)) {
+      std::vector<int> reach(Cf, 0);  // reach[c] = max (c - r) over the blocks of column c of the upper triangle
+      for (int s2 = 0; s2 < nu; ++s2) reach[ucol[s2]] = std::max(reach[ucol[s2]], ucol[s2] - urow[s2]);
+      for (int c = 1; c < Cf; ++c) reach[c] = std::max(reach[c], reach[c - 1]);  // prefix maximum
+      int best_na = -1, best_bw = 0;
+      long best_cost = 0;
+      for (int na = 0; na <= std::min(16, Cf - 1); ++na) {
+        const int bw = std::min(reach[Cf - na - 1], Cf - na - 1);
+        const long width = bw + 1 + na, nrow = width + 1;
+        if (nrow > BND_MAX_NROW || width * nrow > BND_MAX_LDS_BLOCKS) continue;
+        const long cost = width * width;
+        if (best_na < 0 || cost < best_cost) { best_na = na; best_bw = bw; best_cost = cost; }
+      }
+      const bool feasible = best_na >= 0;
+      if (want == BA_SOLVER_BANDED_CHOLESKY) {
+        if (!feasible) return fail(h, BA_ERR_INVALID, "the reduced system is not banded enough for the banded Cholesky solver");
+        h->banded_solve = true;
+      } else if (want == BA_SOLVER_AUTO && feasible && !h->small_solve) {
+        h->banded_solve = 4L * (best_bw + 1 + best_na) <= Cf;  // else the system is as good as dense
+      }
+      if (h->banded_solve) {
+        h->bshape = BandedShape{Cf, Cf - best_na, best_bw, best_na, best_bw + 1 + best_na + 1};
+        h->banded_lds = (size_t)(best_bw + 1 + best_na) * h->bshape.nrow * 36 * sizeof(double) + 1024;  // + pair table
+        HIP_TRY(h, hipFuncSetAttribute((const void*)k_banded_factor, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)h->banded_lds));
+        h->dense_solve = false;
+        h->small_solve = false;
+      }
+    } else if (want == BA_SOLVER_BANDED_CHOLESKY) {
+      return fail(h, BA_ERR_INVALID, "the banded Cholesky solver needs one connected problem with free cameras");
+    }
     if (h->comp_solve || h->dense_solve) h->small_solve = false;
     h->dense_nt = (6 * Cf + DT - 1) / DT;
     if (h->comp_solve && h->comp_lds > 32 * 1024)
@@ -1146,6 +1205,8 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
       (rc = dev_alloc(h, &h->poses_init, (size_t)7 * C)) || (rc = dev_alloc(h, &d.pts_buf[0], (size_t)3 * L)) ||
       (rc = dev_alloc(h, &d.pts_buf[1], (size_t)3 * L)) || (rc = dev_alloc(h, &h->pts_init, (size_t)3 * L)))
     return rc;
+  h->banded_B = nullptr;
+  if (h->banded_solve && (rc = dev_alloc(h, &h->banded_B, (size_t)Cf * h->bshape.nrow * 36))) return rc;
   h->dense_A = nullptr;
   if (h->dense_solve) {
     const size_t ld = (size_t)h->dense_nt * DT;
@@ -1430,7 +1491,7 @@ int ba_debug_linearization(ba_handle* h, const double* poses, const double* poin
   }
   if (S) {
     if ((rc = fetch(t, d.S, (size_t)36 * d.nu))) return rc;
-    if (h->small_solve || h->comp_solve || h->dense_solve) {  // these solvers apply the damping on the fly; add it for the export
+    if (h->small_solve || h->comp_solve || h->dense_solve || h->banded_solve) {  // these solvers apply the damping on the fly; add it for the export
       std::vector<double> ugc, ud((size_t)6 * Cf);
       if ((rc = fetch(ugc, d.Ugc, (size_t)27 * C))) return rc;
       for (int f = 0; f < Cf; ++f)

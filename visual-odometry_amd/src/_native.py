@@ -75,6 +75,7 @@ _SIGNATURES = {
     "ba_triangulate": (C.c_int, [_P, _D, C.c_int32, C.c_double, _D, _D, C.POINTER(C.c_uint8)]),
     "ba_jacobian_blocks": (C.c_int, [_P, _D, _D, _D, _D]),
     "ba_debug_linearization": (C.c_int, [_P, _D, _D, C.c_double] + [_D] * 9),
+    "ba_reduced_solver": (C.c_int, [_P, _I]),
     "ba_schur_block_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "ba_get_kernel_times": (C.c_int, [_P, _D, _I]),
     "ba_set_kernel_timing": (C.c_int, [_P, C.c_int32]),
@@ -305,6 +306,13 @@ class Solver:
 
     def set_kernel_timing(self, on: bool):
         self._check(self._lib.ba_set_kernel_timing(self._h, 1 if on else 0))
+
+    REDUCED_SOLVERS = ("pcg", "pcg_one_workgroup", "dense_cholesky", "banded_cholesky", "component_cholesky")
+
+    def reduced_solver(self) -> str:
+        v = C.c_int32()
+        self._check(self._lib.ba_reduced_solver(self._h, C.byref(v)))
+        return self.REDUCED_SOLVERS[v.value]
 
     def schur_block_count(self) -> int:
         v = C.c_int64()
