@@ -127,11 +127,13 @@ def _open_trajectory(C, L, d):
     return dict(sc, obs_cam=sc["obs_cam"][keep], obs_pt=sc["obs_pt"][keep], obs_uv=sc["obs_uv"][keep])
 
 
+@pytest.mark.parametrize("segments", [0, 4], ids=["one_level", "four_segments"])
 @pytest.mark.parametrize("make", [lambda: scenes.ring_scene(60, 1200, 5), lambda: _open_trajectory(60, 1200, 5)],
                          ids=["closed_loop", "open_trajectory"])
-def test_banded_cholesky_step_matches_oracle(make):
-    """One LM step of the banded + arrow Cholesky (ba_banded.h) against a dense numpy solve of the oracle's
-    reduced system: 1e-9 relative (direct solver)."""
+def test_banded_cholesky_step_matches_oracle(make, segments, monkeypatch):
+    """One LM step of the banded + arrow Cholesky (ba_banded.h), in one level and cut into four segments that
+    are eliminated in parallel, against a dense numpy solve of the oracle's reduced system: 1e-9 relative."""
+    monkeypatch.setenv("BA_BSEG_P", str(segments))
     sc = make()
     C, L = len(sc["poses_gt"]), len(sc["points_gt"])
     poses, pts = sc["poses_guess"], sc["points_guess"]

@@ -292,3 +292,252 @@ __global__ __launch_bounds__(64) void k_banded_backsolve(const double* __restric
     __syncthreads();
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Two-level variant for long trajectories (closed or open): the chain of C block columns is cut into P
+// segments by separators of bw consecutive cameras each (ring order: sep 0 | interior 0 | sep 1 | interior 1 |
+// ... | interior P-1, whose right-hand neighbour is sep 0 again -- the loop closure is just another band
+// coupling).  The interior of a segment only couples with itself and with its two separators, so every
+// segment is a banded problem with an arrow of 2 bw cameras (left separator, right separator) and is
+// eliminated by ITS OWN workgroup, all at the same time (k_bseg_factor: the loop of k_banded_factor over the
+// band columns only).  What the segments leave on their arrow blocks is added to the small system of the
+// P bw separator cameras (k_bseg_corner_add), itself banded + arrow, which the one-workgroup kernels above
+// factor and solve; the segments then back-substitute their interiors, again in parallel (k_bseg_backsolve).
+// Sequential chain: C / P + P bw columns instead of C.
+// Storage: one buffer [segment 0 | segment 1 | ... | level-2 system]; a segment is its interior columns followed
+// by its 2 bw corner columns, all with nrow = bw + 1 + 2 bw + 1 slots.
+struct BandedSeg {
+  long base;       // offset (doubles) of the segment's storage
+  int n_int;       // interior cameras (band columns)
+  int first;       // free-camera index of the first interior camera; its left separator is [first - bw, first)
+};
+
+// The damped S and -rhs to precomputed places: dst[s] = offset of the 6x6 block of upper slot s, tr[s] = store
+// transposed, rdst[f] = offset of the rhs row of free camera f.  B must be zero.
+__global__ __launch_bounds__(256) void k_bseg_assemble(DeviceProblem d, double* __restrict__ B, const long* __restrict__ dst,
+                                                       const unsigned char* __restrict__ tr, const long* __restrict__ rdst,
+                                                       double lam, double min_diag, int solver_mode) {
+  if (solver_mode) {
+    if (d.ctrl->done) return;
+    lam = d.ctrl->lam;
+  }
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nS = (long)d.nu * 36;
+  if (t < nS) {
+    const int s = (int)(t / 36), e = (int)(t - 36L * s), r = e / 6, c = e - 6 * r;
+    const int i = d.urow[s], j = d.ucol[s];
+    double v = d.S[t];
+    double* blk = B + dst[s];
+    if (i == j) {
+      if (c > r) return;
+      if (r == c) v += lam * fmax(u_diag(d, i, r), min_diag);
+      blk[6 * r + c] = v;
+      blk[6 * c + r] = v;
+    } else if (tr[s]) {
+      blk[6 * c + r] = v;
+    } else {
+      blk[6 * r + c] = v;
+    }
+  } else if (t < nS + 6L * d.Cf) {
+    const long p = t - nS;
+    const int k = (int)(p / 6), e = (int)(p - 6L * k);
+    B[rdst[k] + e] = -d.rhs[p];
+  }
+}
+
+// One workgroup per segment: eliminate the band columns (as k_banded_factor does), then write the updated
+// corner columns back.
+__global__ __launch_bounds__(BND_THREADS) void k_bseg_factor(double* __restrict__ Ball, const BandedSeg* __restrict__ segs, int bw,
+                                                             const LmCtrl* ctrl, double* __restrict__ badv) {
+  extern __shared__ double lds[];
+  if (ctrl && ctrl->done) return;
+  const BandedSeg sg = segs[blockIdx.x];
+  const BandedShape sh{sg.n_int + 2 * bw, sg.n_int, bw, 2 * bw, 3 * bw + 2};
+  double* __restrict__ B = Ball + sg.base;
+  const int tid = threadIdx.x;
+  const int cs = sh.nrow * 36, nwin = sh.bw + 1;
+  double* win = lds;
+  auto col_lds = [&](int k) { return win + (long)(k < sh.Cb ? k % nwin : nwin + (k - sh.Cb)) * cs; };
+  for (int k = 0; k < min(nwin, sh.Cb); ++k)
+    for (int e = tid; e < cs; e += BND_THREADS) col_lds(k)[e] = B[(long)k * cs + e];
+  for (int k = sh.Cb; k < sh.Cf; ++k)
+    for (int e = tid; e < cs; e += BND_THREADS) col_lds(k)[e] = B[(long)k * cs + e];
+  unsigned char* pa = (unsigned char*)(win + (long)(nwin + sh.na) * cs);
+  unsigned char* pb = pa + 512;
+  __shared__ int npairs_s;
+  if (tid == 0) {
+    int np = 0;
+    for (int sa = 1; sa < sh.nrow; ++sa)
+      for (int sb = 1; sb <= min(sa, sh.nrow - 2); ++sb) { pa[np] = (unsigned char)sa; pb[np] = (unsigned char)sb; ++np; }
+    npairs_s = np;
+  }
+  __syncthreads();
+  const int npairs = npairs_s;
+  const int pgrp = tid / 36, e0 = tid - 36 * pgrp, rr0 = e0 / 6, cc0 = e0 - 6 * rr0;
+  int jm = 0;
+  bool bad = false;
+  for (int j = 0; j < sh.Cb; ++j) {
+    double* cj = col_lds(j);
+    const int knew = j + nwin;
+    const bool have_new = knew < sh.Cb;
+    double fresh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + q * BND_THREADS;
+      fresh[q] = (have_new && e < cs) ? B[(long)knew * cs + e] : 0.0;
+    }
+    double Li[36];
+    if (!chol6_inverse(cj, Li)) bad = true;
+    const int sl = tid / 6, r = tid - 6 * sl;
+    double out[6];
+    bool mine = false;
+    if (sl < sh.nrow && sl != 0) {
+      const int i = bnd_row_of(sh, j, sl);
+      if (i >= 0 && (i < sh.Cf || r == 0)) {
+        mine = true;
+        const double* src = cj + sl * 36 + 6 * r;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          double t = 0.0;
+#pragma unroll
+          for (int m = 0; m <= c; ++m) t += src[m] * Li[6 * c + m];
+          out[c] = t;
+        }
+      }
+    }
+    if (mine) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) cj[sl * 36 + 6 * r + c] = out[c];
+    }
+    double li_mine = 0.0;
+#pragma unroll
+    for (int e = 0; e < 36; ++e) li_mine = (e == tid) ? Li[e] : li_mine;
+    __syncthreads();
+    for (int p = pgrp < BND_THREADS / 36 ? pgrp : npairs; p < npairs; p += BND_THREADS / 36) {
+      const int sa = pa[p], sb = pb[p];
+      if ((sa <= sh.bw && j + sa >= sh.Cb) || (sb <= sh.bw && j + sb >= sh.Cb)) continue;
+      if (sa == sh.nrow - 1 && rr0 != 0) continue;
+      double* tcol;
+      if (sb <= sh.bw) {
+        int idx = jm + sb;
+        if (idx >= nwin) idx -= nwin;
+        tcol = win + (long)idx * cs;
+      } else {
+        tcol = win + (long)(nwin + sb - sh.bw - 1) * cs;
+      }
+      const int tslot = sa <= sh.bw ? sa - sb : sa;
+      const double* a = cj + sa * 36 + 6 * rr0;
+      const double* b = cj + sb * 36 + 6 * cc0;
+      double t = 0.0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) t += a[m] * b[m];
+      tcol[tslot * 36 + 6 * rr0 + cc0] -= t;
+    }
+    if (++jm == nwin) jm = 0;
+    __syncthreads();
+    if (have_new) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = tid + q * BND_THREADS;
+        if (e < cs) cj[e] = fresh[q];
+      }
+    }
+    if (mine) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) B[(long)j * cs + sl * 36 + 6 * r + c] = out[c];
+    }
+    if (tid < 36) B[(long)j * cs + tid] = li_mine;
+  }
+  __syncthreads();
+  for (int k = sh.Cb; k < sh.Cf; ++k)
+    for (int e = tid; e < cs; e += BND_THREADS) B[(long)k * cs + e] = col_lds(k)[e];
+  if (bad && tid == 0) atomic_add_f64(badv, 1.0);
+}
+
+// What segment b left on its arrow blocks, added to the level-2 system: pair q = (a, a'), a >= a', of its 2 bw
+// arrow cameras goes to cdst[b][q] (transposed if ctr[b][q]); the rhs row of arrow camera a to crdst[b][a].
+// Segments of one parity never share a level-2 block (P is even), so each launch takes one parity and adds
+// with plain read-modify-writes: the sums are bitwise reproducible.
+__global__ __launch_bounds__(256) void k_bseg_corner_add(double* __restrict__ Ball, const BandedSeg* __restrict__ segs, int bw,
+                                                         int parity, const long* __restrict__ cdst,
+                                                         const unsigned char* __restrict__ ctr, const long* __restrict__ crdst,
+                                                         const LmCtrl* ctrl) {
+  if (ctrl && ctrl->done) return;
+  const int b = 2 * blockIdx.x + parity;
+  const BandedSeg sg = segs[b];
+  const int na = 2 * bw, nrow = 3 * bw + 2, cs = nrow * 36, npair = na * (na + 1) / 2;
+  const double* __restrict__ C0 = Ball + sg.base + (long)sg.n_int * cs;  // corner columns
+  for (int w = threadIdx.x; w < npair * 36 + na * 6; w += blockDim.x) {
+    if (w < npair * 36) {
+      const int q = w / 36, e = w - 36 * q, rr = e / 6, cc = e - 6 * rr;
+      int a = 0;
+      while ((a + 1) * (a + 2) / 2 <= q) ++a;  // q = a (a + 1) / 2 + a'
+      const int a2 = q - a * (a + 1) / 2;
+      const double v = C0[(long)a2 * cs + (bw + 1 + a) * 36 + 6 * rr + cc];  // block (row a, col a')
+      double* dstp = Ball + cdst[(long)b * npair + q];
+      // the level-2 system already holds the assembled (damped) blocks; a segment's diagonal corner blocks
+      // were kept full, so both triangles are added there
+      if (ctr[(long)b * npair + q]) dstp[6 * cc + rr] += v; else dstp[6 * rr + cc] += v;
+    } else {
+      const int w2 = w - npair * 36, a = w2 / 6, e = w2 - 6 * a;
+      Ball[crdst[(long)b * na + a] + e] += C0[(long)a * cs + (long)(nrow - 1) * 36 + e];
+    }
+  }
+}
+
+// Interiors of all segments, one wave each: x of the segment's separators comes from the level-2 solution x2
+// (level-2 index of arrow camera a of segment b: l2[b][a]); writes x of the interior and of the left separator
+// to x_out [Cf][6].
+__global__ __launch_bounds__(64) void k_bseg_backsolve(const double* __restrict__ Ball, const BandedSeg* __restrict__ segs, int bw,
+                                                       const int* __restrict__ l2, const double* __restrict__ x2,
+                                                       const LmCtrl* ctrl, double* __restrict__ x_out) {
+  extern __shared__ double lds[];
+  if (ctrl && ctrl->done) return;
+  const BandedSeg sg = segs[blockIdx.x];
+  const BandedShape sh{sg.n_int + 2 * bw, sg.n_int, bw, 2 * bw, 3 * bw + 2};
+  const double* __restrict__ B = Ball + sg.base;
+  const int lane = threadIdx.x;
+  const int cs = sh.nrow * 36, nwin = sh.bw + 1;
+  double* xr = lds;
+  double* xa = xr + nwin * 6;
+  double* part = xa + sh.na * 6;
+  for (int w = lane; w < sh.na * 6; w += 64) {
+    const int a = w / 6, e = w - 6 * a;
+    const double v = x2[6L * l2[(long)blockIdx.x * sh.na + a] + e];
+    xa[w] = v;
+    if (a < bw) x_out[6L * (sg.first - bw + a) + e] = v;  // the left separator's cameras
+  }
+  __syncthreads();
+  auto xptr = [&](int i) { return i < sh.Cb ? xr + (i % nwin) * 6 : xa + (i - sh.Cb) * 6; };
+  const int g = lane / 6, c = lane - 6 * g;
+  for (int j = sh.Cb - 1; j >= 0; --j) {
+    const double* cj = B + (long)j * cs;
+    double acc = 0.0;
+    if (g < 10) {
+      for (int sl = g; sl < sh.nrow - 1; sl += 10) {
+        const int i = bnd_row_of(sh, j, sl);
+        if (i < 0) continue;
+        const double* L = cj + sl * 36;
+        const double* xi = xptr(i);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc += L[6 * r + c] * xi[r];
+      }
+      part[g * 6 + c] = acc;
+    }
+    __syncthreads();
+    if (lane < 6) {
+      double t = cj[(sh.nrow - 1) * 36 + lane];
+      for (int q = 0; q < 10; ++q) t -= part[q * 6 + lane];
+      part[60 + lane] = t;
+    }
+    __syncthreads();
+    if (lane < 6) {
+      double x = 0.0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) x += (m >= lane) ? cj[6 * m + lane] * part[60 + m] : 0.0;
+      xptr(j)[lane] = x;
+      x_out[6L * (sg.first + j) + lane] = x;
+    }
+    __syncthreads();
+  }
+}

@@ -90,6 +90,17 @@ struct ba_handle {
   BandedShape bshape{};
   double* banded_B = nullptr;
   size_t banded_lds = 0;
+  // two-level (segmented) variant: P segments in parallel + a level-2 system of the separators
+  int bseg_P = 0, bseg_bw = 0;
+  long bseg_base2 = 0, bseg_total = 0;
+  size_t bseg_lds = 0;
+  const BandedSeg* bseg_segs = nullptr;
+  const long* bseg_dst = nullptr; const unsigned char* bseg_tr = nullptr; const long* bseg_rdst = nullptr;
+  const long* bseg_cdst = nullptr; const unsigned char* bseg_ctr = nullptr; const long* bseg_crdst = nullptr;
+  const int* bseg_l2 = nullptr;
+  double* bseg_x2 = nullptr;
+  std::vector<BandedSeg> h_segs; std::vector<long> h_dst, h_rdst, h_cdst, h_crdst; std::vector<unsigned char> h_tr, h_ctr;
+  std::vector<int> h_l2;
   double* dense_A = nullptr;
   int dense_nt = 0;
   size_t small_lds = 0;
@@ -363,6 +374,28 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
   const double tol2 = o.pcg_tol * o.pcg_tol;
   if (h->comp_solve) {
     launch_timed_lds(h, KT_PCG, k_solve_components, d.n_comp, 64, h->comp_lds, d, lam, o.min_diag);
+    *pcg_iters = -1;
+    return BA_OK;
+  }
+  if (h->banded_solve && h->bseg_P > 0) {
+    const LmCtrl* ctrl = mode ? d.ctrl : nullptr;
+    const BandedShape& sh2 = h->bshape;  // the level-2 system
+    const int P = h->bseg_P, bw = h->bseg_bw;
+    double* Ball = h->banded_B;
+    HIP_TRY(h, hipMemsetAsync(Ball, 0, (size_t)h->bseg_total * sizeof(double), h->stream));
+    launch_timed(h, KT_PCG, k_bseg_assemble, grid_for((long)d.nu * 36 + 6L * d.Cf), 256, d, Ball, h->bseg_dst, h->bseg_tr,
+                 h->bseg_rdst, lam, o.min_diag, mode);
+    launch_timed_lds(h, KT_PCG, k_bseg_factor, P, BND_THREADS, h->bseg_lds, Ball, h->bseg_segs, bw, ctrl, d.scal + SC_BADV);
+    for (int parity = 0; parity < 2; ++parity)
+      launch_timed(h, KT_PCG, k_bseg_corner_add, P / 2, 256, Ball, h->bseg_segs, bw, parity, h->bseg_cdst, h->bseg_ctr,
+                   h->bseg_crdst, ctrl);
+    launch_timed_lds(h, KT_PCG, k_banded_factor, 1, BND_THREADS, h->banded_lds, Ball + h->bseg_base2, sh2, ctrl,
+                     d.scal + SC_BADV);
+    launch_timed_lds(h, KT_PCG, k_banded_backsolve, 1, 64,
+                     (size_t)((sh2.bw + 1 + std::max(sh2.na, 1)) * 6 + 66) * sizeof(double),
+                     (const double*)(Ball + h->bseg_base2), sh2, ctrl, h->bseg_x2);
+    launch_timed_lds(h, KT_PCG, k_bseg_backsolve, P, 64, (size_t)((bw + 1 + 2 * bw) * 6 + 66) * sizeof(double),
+                     (const double*)Ball, h->bseg_segs, bw, h->bseg_l2, (const double*)h->bseg_x2, ctrl, d.dc);
     *pcg_iters = -1;
     return BA_OK;
   }
@@ -1115,20 +1148,29 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
     // banded + arrow shape of the pattern in the camera order: for every arrow size na, the half-bandwidth of the
     // blocks that lie outside the last na rows; the cheapest window wins
     h->banded_solve = false;
-    if (Cf > 0 && !h->comp_solve && env_int("BA_BANDED_SOLVE", 1)) {
-      std::vector<int> reach(Cf, 0);  // reach[c] = max (c - r) over the blocks of column c of the upper triangle
-      for (int s2 = 0; s2 < nu; ++s2) reach[ucol[s2]] = std::max(reach[ucol[s2]], ucol[s2] - urow[s2]);
-      for (int c = 1; c < Cf; ++c) reach[c] = std::max(reach[c], reach[c - 1]);  // prefix maximum
+    h->bseg_P = 0;
+    // best (bw, na) for n cameras whose upper-triangle blocks are `pairs` (r <= c); false if nothing fits the LDS
+    auto choose_shape = [](int n, const std::vector<std::pair<int, int>>& pairs, int* bw_out, int* na_out) {
+      std::vector<int> reach(n, 0);  // reach[c] = max (c - r) over the blocks of column c, then prefix maximum
+      for (const auto& rc : pairs) reach[rc.second] = std::max(reach[rc.second], rc.second - rc.first);
+      for (int c = 1; c < n; ++c) reach[c] = std::max(reach[c], reach[c - 1]);
       int best_na = -1, best_bw = 0;
       long best_cost = 0;
-      for (int na = 0; na <= std::min(16, Cf - 1); ++na) {
-        const int bw = std::min(reach[Cf - na - 1], Cf - na - 1);
+      for (int na = 0; na <= std::min(16, n - 1); ++na) {
+        const int bw = std::min(reach[n - na - 1], n - na - 1);
         const long width = bw + 1 + na, nrow = width + 1;
         if (nrow > BND_MAX_NROW || width * nrow > BND_MAX_LDS_BLOCKS) continue;
         const long cost = width * width;
         if (best_na < 0 || cost < best_cost) { best_na = na; best_bw = bw; best_cost = cost; }
       }
-      const bool feasible = best_na >= 0;
+      *bw_out = best_bw; *na_out = best_na;
+      return best_na >= 0;
+    };
+    if (Cf > 0 && !h->comp_solve && env_int("BA_BANDED_SOLVE", 1)) {
+      std::vector<std::pair<int, int>> pairs(nu);
+      for (int s2 = 0; s2 < nu; ++s2) pairs[s2] = {urow[s2], ucol[s2]};
+      int best_bw = 0, best_na = -1;
+      const bool feasible = choose_shape(Cf, pairs, &best_bw, &best_na);
       if (want == BA_SOLVER_BANDED_CHOLESKY) {
         if (!feasible) return fail(h, BA_ERR_INVALID, "the reduced system is not banded enough for the banded Cholesky solver");
         h->banded_solve = true;
@@ -1137,11 +1179,109 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
       }
       if (h->banded_solve) {
         h->bshape = BandedShape{Cf, Cf - best_na, best_bw, best_na, best_bw + 1 + best_na + 1};
-        h->banded_lds = (size_t)(best_bw + 1 + best_na) * h->bshape.nrow * 36 * sizeof(double) + 1024;  // + pair table
-        HIP_TRY(h, hipFuncSetAttribute((const void*)k_banded_factor, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)h->banded_lds));
         h->dense_solve = false;
         h->small_solve = false;
+        // ---- two-level plan (ba_banded.h): ring bandwidth, P segments, where every block goes
+        int bwr = 0;
+        for (int s2 = 0; s2 < nu; ++s2) bwr = std::max(bwr, std::min(ucol[s2] - urow[s2], Cf - (ucol[s2] - urow[s2])));
+        int P = env_int("BA_BSEG_P", (int)std::lround(std::sqrt((double)Cf / (2.0 * std::max(bwr, 1)))));
+        P = std::min(P & ~1, 256);
+        bool two = env_int("BA_BSEG", 1) && bwr >= 1 && P >= 4 && Cf / P >= 3 * bwr + 1 && 3 * bwr + 2 <= BND_MAX_NROW &&
+                   (long)(3 * bwr + 1) * (3 * bwr + 2) <= BND_MAX_LDS_BLOCKS;
+        if (two) {
+          const int bw = bwr, na_s = 2 * bw, nrow_s = 3 * bw + 2, npair = na_s * (na_s + 1) / 2;
+          const long cs_s = (long)nrow_s * 36;
+          std::vector<int> sp(P + 1);
+          for (int q = 0; q <= P; ++q) sp[q] = (int)((long)q * Cf / P);
+          std::vector<int> seg_of(Cf), loc(Cf);  // separator camera: seg_of = -1 - p, loc = t; interior: seg_of = p, loc = column
+          h->h_segs.assign(P, BandedSeg{});
+          long off = 0;
+          for (int q = 0; q < P; ++q) {
+            const int n_int = sp[q + 1] - sp[q] - bw;
+            h->h_segs[q] = BandedSeg{off, n_int, sp[q] + bw};
+            off += (long)(n_int + na_s) * cs_s;
+            for (int f = sp[q]; f < sp[q + 1]; ++f) {
+              if (f < sp[q] + bw) { seg_of[f] = -1 - q; loc[f] = f - sp[q]; }
+              else { seg_of[f] = q; loc[f] = f - sp[q] - bw; }
+            }
+          }
+          const long base2 = off;
+          // level-2 pattern: every pair inside sep p U sep p + 1
+          const int n2 = P * bw;
+          std::vector<std::pair<int, int>> pairs2;
+          for (int q = 0; q < P; ++q) {
+            std::vector<int> cams;
+            for (int t = 0; t < bw; ++t) cams.push_back(q * bw + t);
+            for (int t = 0; t < bw; ++t) cams.push_back(((q + 1) % P) * bw + t);
+            for (int a : cams) for (int b2 : cams) if (a <= b2) pairs2.push_back({a, b2});
+          }
+          int bw2 = 0, na2 = -1;
+          two = choose_shape(n2, pairs2, &bw2, &na2);
+          if (two) {
+            const BandedShape sh2{n2, n2 - na2, bw2, na2, bw2 + 1 + na2 + 1};
+            const long cs2 = (long)sh2.nrow * 36;
+            auto l2_of = [&](int f) { return (-1 - seg_of[f]) * bw + loc[f]; };
+            auto dst2 = [&](int i2, int k2) {  // block (i2, k2), i2 >= k2, of the level-2 system
+              const int slot = i2 == k2 ? bnd_diag_slot(sh2, k2) : bnd_slot(sh2, i2, k2);
+              if (k2 < sh2.Cb && i2 < sh2.Cb && i2 - k2 > sh2.bw) two = false;
+              return base2 + k2 * cs2 + (long)slot * 36;
+            };
+            h->h_dst.assign(nu, 0); h->h_tr.assign(nu, 0); h->h_rdst.assign(Cf, 0);
+            for (int s2 = 0; s2 < nu && two; ++s2) {
+              const int r = urow[s2], c = ucol[s2];
+              const bool ri = seg_of[r] >= 0, ci = seg_of[c] >= 0;
+              if (ri && ci) {
+                if (seg_of[r] != seg_of[c] || c - r > bw) { two = false; break; }
+                h->h_dst[s2] = h->h_segs[seg_of[r]].base + loc[r] * cs_s + (long)(c - r) * 36;
+                h->h_tr[s2] = 1;
+              } else if (ri) {  // c is a camera of the right separator of r's segment
+                const int q = seg_of[r], pc = -1 - seg_of[c];
+                if (pc != (q + 1) % P) { two = false; break; }
+                h->h_dst[s2] = h->h_segs[q].base + loc[r] * cs_s + (long)(bw + 1 + bw + loc[c]) * 36;
+                h->h_tr[s2] = 1;
+              } else if (ci) {  // r is a separator camera: the left one of c's segment, or (wrap) the right one
+                const int q = seg_of[c], pr = -1 - seg_of[r];
+                int a;
+                if (pr == q) a = loc[r];
+                else if (pr == (q + 1) % P) a = bw + loc[r];
+                else { two = false; break; }
+                h->h_dst[s2] = h->h_segs[q].base + loc[c] * cs_s + (long)(bw + 1 + a) * 36;
+                h->h_tr[s2] = 0;
+              } else {
+                h->h_dst[s2] = dst2(l2_of(c), l2_of(r));
+                h->h_tr[s2] = 1;
+              }
+            }
+            for (int f = 0; f < Cf && two; ++f)
+              h->h_rdst[f] = seg_of[f] >= 0 ? h->h_segs[seg_of[f]].base + loc[f] * cs_s + (long)(nrow_s - 1) * 36
+                                            : base2 + l2_of(f) * cs2 + (long)(sh2.nrow - 1) * 36;
+            h->h_l2.assign((size_t)P * na_s, 0);
+            h->h_cdst.assign((size_t)P * npair, 0); h->h_ctr.assign((size_t)P * npair, 0); h->h_crdst.assign((size_t)P * na_s, 0);
+            for (int q = 0; q < P && two; ++q) {
+              for (int a = 0; a < na_s; ++a) {
+                h->h_l2[(size_t)q * na_s + a] = a < bw ? q * bw + a : ((q + 1) % P) * bw + (a - bw);
+                h->h_crdst[(size_t)q * na_s + a] = base2 + h->h_l2[(size_t)q * na_s + a] * cs2 + (long)(sh2.nrow - 1) * 36;
+              }
+              for (int a = 0; a < na_s; ++a)
+                for (int a2 = 0; a2 <= a; ++a2) {
+                  const int i2 = h->h_l2[(size_t)q * na_s + a], k2 = h->h_l2[(size_t)q * na_s + a2];
+                  const size_t qi = (size_t)q * npair + (size_t)a * (a + 1) / 2 + a2;
+                  if (i2 >= k2) { h->h_cdst[qi] = dst2(i2, k2); h->h_ctr[qi] = 0; }
+                  else { h->h_cdst[qi] = dst2(k2, i2); h->h_ctr[qi] = 1; }
+                }
+            }
+            if (two) {
+              h->bseg_P = P; h->bseg_bw = bw; h->bseg_base2 = base2; h->bseg_total = base2 + (long)n2 * cs2;
+              h->bseg_lds = (size_t)(bw + 1 + na_s) * nrow_s * 36 * sizeof(double) + 1024;
+              h->bshape = sh2;
+              HIP_TRY(h, hipFuncSetAttribute((const void*)k_bseg_factor, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)h->bseg_lds));
+            }
+          }
+        }
+        h->banded_lds = (size_t)(h->bshape.bw + 1 + h->bshape.na) * h->bshape.nrow * 36 * sizeof(double) + 1024;  // + pair table
+        HIP_TRY(h, hipFuncSetAttribute((const void*)k_banded_factor, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)h->banded_lds));
       }
     } else if (want == BA_SOLVER_BANDED_CHOLESKY) {
       return fail(h, BA_ERR_INVALID, "the banded Cholesky solver needs one connected problem with free cameras");
@@ -1206,7 +1346,16 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
       (rc = dev_alloc(h, &d.pts_buf[1], (size_t)3 * L)) || (rc = dev_alloc(h, &h->pts_init, (size_t)3 * L)))
     return rc;
   h->banded_B = nullptr;
-  if (h->banded_solve && (rc = dev_alloc(h, &h->banded_B, (size_t)Cf * h->bshape.nrow * 36))) return rc;
+  if (h->banded_solve && h->bseg_P > 0) {
+    if ((rc = dev_alloc(h, &h->banded_B, (size_t)h->bseg_total)) || (rc = dev_alloc(h, &h->bseg_x2, (size_t)6 * h->bshape.Cf)) ||
+        (rc = dev_upload(h, &h->bseg_segs, h->h_segs)) || (rc = dev_upload(h, &h->bseg_dst, h->h_dst)) ||
+        (rc = dev_upload(h, &h->bseg_tr, h->h_tr)) || (rc = dev_upload(h, &h->bseg_rdst, h->h_rdst)) ||
+        (rc = dev_upload(h, &h->bseg_cdst, h->h_cdst)) || (rc = dev_upload(h, &h->bseg_ctr, h->h_ctr)) ||
+        (rc = dev_upload(h, &h->bseg_crdst, h->h_crdst)) || (rc = dev_upload(h, &h->bseg_l2, h->h_l2)))
+      return rc;
+  } else if (h->banded_solve && (rc = dev_alloc(h, &h->banded_B, (size_t)Cf * h->bshape.nrow * 36))) {
+    return rc;
+  }
   h->dense_A = nullptr;
   if (h->dense_solve) {
     const size_t ld = (size_t)h->dense_nt * DT;
