@@ -173,3 +173,21 @@ def test_banded_cholesky_rejects_unstructured_problems():
     with _native.Solver(linear_solver=3) as s:
         with pytest.raises(Exception):
             s.set_problem(200, 4000, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+
+
+@pytest.mark.parametrize("d,segments", [(3, 4), (3, 8), (4, 6), (7, 6)])
+def test_banded_cholesky_other_bandwidths(d, segments, monkeypatch):
+    """Track lengths 3 / 4 / 7 (half-bandwidths 2 / 3 / 6) with forced segment counts; where the separators'
+    system does not fit the LDS window (d = 7) the solver stays on one level.  Same bar: 1e-9 of a dense solve."""
+    monkeypatch.setenv("BA_BSEG_P", str(segments))
+    sc = scenes.ring_scene(120, 2400, d)
+    C, L = 120, 2400
+    poses, pts = sc["poses_guess"], sc["points_guess"]
+    lam = 1e-2
+    with _native.Solver(linear_solver=3) as s:
+        s.set_problem(C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+        out = s.debug_linearization(poses, pts, lam, want_S=True)
+    S, rhs = out["S"], out["rhs"]
+    dc = np.linalg.solve(S, -rhs).reshape(C, 6)
+    dc[0] = 0.0
+    np.testing.assert_allclose(out["dc"], dc, rtol=0, atol=1e-9 * np.abs(dc).max())
