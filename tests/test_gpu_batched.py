@@ -191,3 +191,25 @@ def test_banded_cholesky_other_bandwidths(d, segments, monkeypatch):
     dc = np.linalg.solve(S, -rhs).reshape(C, 6)
     dc[0] = 0.0
     np.testing.assert_allclose(out["dc"], dc, rtol=0, atol=1e-9 * np.abs(dc).max())
+
+
+def test_banded_cholesky_on_a_small_dense_pattern(golden):
+    """Forced on a problem whose cameras all see each other (9 free cameras: the band is the whole matrix) and
+    on a two-camera problem (one free camera): still an exact solver, converged cost as the default solver's."""
+    g = golden("noisy_10x300")
+    n_poses = len(g["poses_gt"]) - 1
+    poses = np.vstack([g["pose0"][None], g["x0"][: 7 * n_poses].reshape(-1, 7)])
+    pts = g["x0"][7 * n_poses:].reshape(-1, 3)
+    with _native.Solver(linear_solver=3) as s:
+        s.set_problem(n_poses + 1, len(pts), g["obs_cam"], g["obs_pt"], g["obs_uv"], g["intr"])
+        assert s.reduced_solver() == "banded_cholesky"
+        _, _, rep = s.solve(poses, pts)
+    pol = float(g["polished_cost"])
+    assert abs(rep["cost"] - pol) <= 1e-6 * pol
+    two = g["obs_cam"] < 2
+    costs = []
+    for ls in (0, 3):
+        with _native.Solver(linear_solver=ls, ftol=1e-12) as s:
+            s.set_problem(2, len(pts), g["obs_cam"][two], g["obs_pt"][two], g["obs_uv"][two], g["intr"])
+            costs.append(s.solve(poses[:2], pts)[2]["cost"])
+    assert abs(costs[0] - costs[1]) <= 1e-8 * costs[0]
