@@ -1159,7 +1159,10 @@ __global__ __launch_bounds__(256) void k_gather_S(DeviceProblem d, int solver_mo
     if (e < 27) {
       if (from_slabs) {
         const long tot = (long)d.C * 27;
-        for (int k = g; k < d.nslab_u; k += 8) u += d.Ugc_slab[(long)k * tot + cam27 + e];
+        for (int k = g; k < d.nslab_u; k += 8) {
+          u += d.Ugc_slab[(long)k * tot + cam27 + e];
+          d.Ugc_slab[(long)k * tot + cam27 + e] = 0.0;  // consumed: clean for the next linearisation (no memset per iteration)
+        }
       } else if (g == 0) {
         u = d.Ugc_part[cam27 + e];
       }
@@ -1881,6 +1884,12 @@ __global__ __launch_bounds__(256) void k_lm_decide(DeviceProblem d, const double
         const double x = d.scal[(size_t)(g * (SCAL_SLABS / 8) + k) * SC_COUNT + i];
         v = is_max ? fmax(v, x) : v + x;
       }
+    }
+    // the statistics are consumed here: leave the accumulators clean for the next iteration (the PCG's own
+    // slots, >= SC_NSUM, are written by the solver itself)
+    if (i < SC_NSUM) {
+#pragma unroll
+      for (int k = 0; k < SCAL_SLABS / 8; ++k) d.scal[(size_t)(g * (SCAL_SLABS / 8) + k) * SC_COUNT + i] = 0.0;
     }
     part[g][i] = v;
   }

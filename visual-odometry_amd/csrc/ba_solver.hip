@@ -556,12 +556,17 @@ int lm_solve(ba_handle* h, ba_report* rep) {
   h->mirror->seq = 0;
   int enq = 0, rc;
   bool done = false;
+  // On the staged path with a solver that keeps no state in the scalar block, the accumulators clean themselves
+  // (k_gather_S zeroes the U / gc slabs it has summed, k_lm_decide the statistics it has folded): one memset per
+  // solve instead of one per iteration.
+  const bool self_cleaning = h->schur_cpb > 0 && (h->small_solve || h->comp_solve || h->dense_solve || h->banded_solve);
+  if ((rc = clear_accumulators(h, true))) return rc;
   while (!done && enq < o.max_iters) {
     const int nb = std::min(check_every, o.max_iters - enq);
     for (int i = 0; i < nb; ++i, ++enq) {
       h->span_iter = enq;
       // a linearisation may or may not run in this iteration (device decides): always clear its slabs
-      if ((rc = clear_accumulators(h, true))) return rc;
+      if (!self_cleaning && enq > 0 && (rc = clear_accumulators(h, true))) return rc;
       enqueue_linearize(h, nullptr, nullptr);
       int pcg_it = 0;
       if ((rc = do_reduced_solve(h, -1.0, &pcg_it))) return rc;
