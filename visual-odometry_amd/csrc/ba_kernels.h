@@ -430,6 +430,23 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_f
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_init_solve: everything a solve needs before its first iteration, in one launch instead of a control-block
+// upload, three device copies and a memset: the initial guess into the current buffers (points also into the
+// trial buffer: landmarks nobody observes are never written again), the LM control head, clean accumulators.
+__global__ __launch_bounds__(256) void k_init_solve(DeviceProblem d, const double* __restrict__ poses_init,
+                                                    const double* __restrict__ pts_init, LmHead head, long n_clear) {
+  const long t0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+  for (long t = t0; t < 7L * d.C; t += stride) d.poses_buf[0][t] = poses_init[t];
+  for (long t = t0; t < 3L * d.L; t += stride) {
+    const double v = pts_init[t];
+    d.pts_buf[0][t] = v;
+    d.pts_buf[1][t] = v;
+  }
+  for (long t = t0; t < n_clear; t += stride) d.Ugc_slab[t] = 0.0;  // [U / gc slabs | scalar copies | S slabs]
+  if (t0 == 0) *static_cast<LmHead*>(d.ctrl) = head;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_cost: residuals only (trial-point evaluation, ba_evaluate).  24 B/obs (+ cached P, pose).
 // Flat over observations; the landmark of observation k is found from o_lm[k].
 template <bool ROBUST>

@@ -537,7 +537,6 @@ int lm_solve(ba_handle* h, ba_report* rep) {
   std::memset(rep, 0, sizeof *rep);
   rep->nobs = (int32_t)h->n_global;
   rep->setup_ms = h->setup_ms;
-  const size_t pose_bytes = (size_t)h->C * 7 * sizeof(double), pts_bytes = (size_t)h->L * 3 * sizeof(double);
   LmCtrl& c = *h->ctrl_host;
   std::memset(&c, 0, sizeof c);
   c.ftol = o.ftol; c.xtol = o.xtol; c.gtol = o.gtol;
@@ -546,10 +545,12 @@ int lm_solve(ba_handle* h, ba_report* rep) {
   c.lam = o.lambda0; c.nu = 2.0; c.need_lin = 1;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   const auto t0 = clk::now();
-  HIP_TRY(h, hipMemcpyAsync(d.ctrl, &c, sizeof c, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(d.poses_buf[0], h->poses_init, pose_bytes, hipMemcpyDeviceToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(d.pts_buf[0], h->pts_init, pts_bytes, hipMemcpyDeviceToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(d.pts_buf[1], h->pts_init, pts_bytes, hipMemcpyDeviceToDevice, h->stream));
+  {
+    const long n_clear = (long)d.nslab_u * h->C * 27 + (long)(SCAL_BYTES / sizeof(double)) + (long)d.nslab_s * d.s_slab_stride;
+    const long work = std::max<long>(3L * h->L, n_clear);
+    k_init_solve<<<(int)std::min<long>(1024, (work + 255) / 256), 256, 0, h->stream>>>(
+        d, (const double*)h->poses_init, (const double*)h->pts_init, static_cast<const LmHead&>(c), n_clear);
+  }
 
   const int check_every =
       (h->small_solve || h->comp_solve || h->dense_solve || h->banded_solve) ? std::max(1, o.lm_check_every) : 1;
@@ -560,7 +561,6 @@ int lm_solve(ba_handle* h, ba_report* rep) {
   // (k_gather_S zeroes the U / gc slabs it has summed, k_lm_decide the statistics it has folded): one memset per
   // solve instead of one per iteration.
   const bool self_cleaning = h->schur_cpb > 0 && (h->small_solve || h->comp_solve || h->dense_solve || h->banded_solve);
-  if ((rc = clear_accumulators(h, true))) return rc;
   while (!done && enq < o.max_iters) {
     const int nb = std::min(check_every, o.max_iters - enq);
     for (int i = 0; i < nb; ++i, ++enq) {
