@@ -78,6 +78,7 @@ struct DeviceProblem {
   const int* bcol;       // [nb]
   const int* bslot;      // [nb]
   const int* sm_slot;    // [nu]  upper slots in diagonal-major order (k_solve_small item order)
+  const int* sm_desc;    // [nu][4] per item: slot, row camera i, column camera j, 27 * camera of i (one load instead of a chain)
   const int* sm_gidx;    // [nb]  k_solve_small gather list, in brow_ptr order: LDS slot offset of each block of a row
   // connected components of the camera graph (k_solve_components)
   const int* comp_ptr;       // [n_comp + 1] into comp_cams
@@ -1428,14 +1429,15 @@ constexpr int SMALL_CSTRIDE = 13;        // doubles per SpMV slot: B z_j (6) | B
 
 __device__ __forceinline__ void small_load_block(const DeviceProblem& d, int t, double lam, double min_diag,
                                                  double B[36], int& i, int& j) {
-  const int s = d.sm_slot[t];
-  i = d.urow[s];
-  j = d.ucol[s];
+  const int4 ds = reinterpret_cast<const int4*>(d.sm_desc)[t];
+  const int s = ds.x;
+  i = ds.y;
+  j = ds.z;
 #pragma unroll
   for (int e = 0; e < 36; ++e) B[e] = d.S[(long)s * 36 + e];
   if (i == j) {
 #pragma unroll
-    for (int e = 0; e < 6; ++e) B[7 * e] += lam * fmax(u_diag(d, i, e), min_diag);
+    for (int e = 0; e < 6; ++e) B[7 * e] += lam * fmax(d.Ugc[ds.w + sym6_index(e, e)], min_diag);
   }
 }
 

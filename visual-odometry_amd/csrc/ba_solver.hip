@@ -1302,6 +1302,12 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
   std::vector<int> fixed_cams;
   for (int c = 0; c < C; ++c)
     if (h->cam2free[c] < 0) fixed_cams.push_back(c);
+  std::vector<int> sm_desc((size_t)4 * std::max(nu, 1), 0);
+  for (int t = 0; t < nu; ++t) {
+    const int s2 = sm_slot[t];
+    sm_desc[4 * (size_t)t] = s2; sm_desc[4 * (size_t)t + 1] = urow[s2]; sm_desc[4 * (size_t)t + 2] = ucol[s2];
+    sm_desc[4 * (size_t)t + 3] = h->free2cam[urow[s2]] * 27;
+  }
   DeviceProblem& d = h->d;
   const int nslab_u = d.nslab_u, nslab_s = d.nslab_s;
   d.C = C; d.Cf = Cf; d.L = L; d.L_obs = L_obs; d.n = n;
@@ -1325,6 +1331,7 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
       (rc = dev_upload(h, &d.diag_slot, diag_slot)) || (rc = dev_upload(h, &d.low_of, low_of)) ||
       (rc = dev_upload(h, &d.brow_ptr, brow_ptr)) || (rc = dev_upload(h, &d.bcol, bcol)) ||
       (rc = dev_upload(h, &d.bslot, bslot)) || (rc = dev_upload(h, &d.sm_slot, sm_slot)) ||
+      (rc = dev_upload(h, &d.sm_desc, sm_desc)) ||
       (rc = dev_upload(h, &d.sm_gidx, sm_gidx)) ||
       (rc = dev_upload(h, &d.comp_ptr, comp_ptr)) || (rc = dev_upload(h, &d.comp_cams, comp_cams)) ||
       (rc = dev_upload(h, &d.comp_local, comp_local)) || (rc = dev_upload(h, &d.comp_slot_ptr, comp_slot_ptr)) ||
