@@ -1,0 +1,59 @@
+"""One rank of tests/test_gpu_two_ranks.py (not collected by pytest).  Started with the test stand-in for
+librccl.so first on LD_LIBRARY_PATH, so that several ranks can share GPU 0; does exactly what bench.py does at
+N > 1: join the communicator, take its landmark shard, solve, and write its part of the estimate."""
+
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (os.path.join(ROOT, "visual-odometry_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def main():
+    rank, world, workdir, scene_name = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    options = {k: (float(v) if "." in v or "e" in v else int(v)) for k, v in (a.split("=") for a in sys.argv[5:])}
+    import scenes
+    import sharding
+    from src import _native
+
+    uid_path = os.path.join(workdir, "uid.bin")
+    if rank == 0:
+        uid = _native.comm_unique_id()
+        with open(uid_path + ".tmp", "wb") as fh:
+            fh.write(uid)
+        os.replace(uid_path + ".tmp", uid_path)
+    else:
+        deadline = time.time() + 60.0
+        while not os.path.exists(uid_path):
+            if time.time() > deadline:
+                raise SystemExit("rank 0 never published the unique id")
+            time.sleep(0.01)
+        with open(uid_path, "rb") as fh:
+            uid = fh.read()
+
+    if scene_name == "ring":
+        sc = scenes.ring_scene(50, 2000, 10)
+    elif scene_name == "ring_long":
+        sc = scenes.ring_scene(300, 3000, 6)
+    else:
+        sc = scenes.noisy_scene(8, 400)
+    C = len(sc["poses_guess"])
+    sh, _ = sharding.shard_arrays(sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["points_guess"], rank, world)
+    with _native.Solver(device=0, **options) as s:
+        s.comm_init(rank, world, uid)
+        s.set_problem(C, len(sh["points"]), sh["obs_cam"], sh["obs_pt"], sh["obs_uv"], sc["intr"])
+        P, X, rep = s.solve(sc["poses_guess"], sh["points"])
+        kind = s.reduced_solver()
+    np.savez(os.path.join(workdir, f"rank{rank}.npz"), poses=P, points=X, lo=sh["lm_lo"], hi=sh["lm_hi"],
+             cost=rep["cost"], cost0=rep["cost0"], iterations=rep["iterations"], status=rep["status"],
+             nobs=rep["nobs"], solver=kind)
+
+
+if __name__ == "__main__":
+    main()

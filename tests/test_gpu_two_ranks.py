@@ -1,0 +1,103 @@
+"""The landmark-sharded solve with MORE than one rank, on the one-GPU test box.
+
+RCCL refuses two ranks on one device, so the rank processes are started with tests/fake_rccl (a test-only stand-in
+for librccl.so that does each collective through host shared memory) first on LD_LIBRARY_PATH.  What runs is the
+library's real multi-rank code: the union of the ranks' block patterns, the all-reduce of [S | rhs | U, gc] in every
+LM iteration, the folded statistics, the device-side LM control on every rank.  The sharded estimate must agree with
+the single-GPU solve of the same scene."""
+
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import scenes
+from src import _native
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SHIM_DIR = os.path.join(HERE, "fake_rccl")
+
+
+def run_ranks(world, scene_name, tmp_path, **options):
+    assert os.path.exists(os.path.join(SHIM_DIR, "librccl.so")), "run __graft_entry__.build() first"
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = SHIM_DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    args = [f"{k}={v}" for k, v in options.items()]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_two_rank_worker.py"), str(r), str(world),
+                               str(tmp_path), scene_name] + args, env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=100)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-2000:]}"
+    return [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+
+
+def single_gpu(sc, **options):
+    with _native.Solver(**options) as s:
+        s.set_problem(len(sc["poses_guess"]), len(sc["points_guess"]), sc["obs_cam"], sc["obs_pt"], sc["obs_uv"],
+                      sc["intr"])
+        return s.solve(sc["poses_guess"], sc["points_guess"])
+
+
+def check_against_single(parts, sc, P0, X0, rep0, atol):
+    for part in parts:
+        # replicated quantities are identical on every rank
+        assert float(part["cost"]) == float(parts[0]["cost"])
+        assert int(part["iterations"]) == int(parts[0]["iterations"])
+        np.testing.assert_array_equal(part["poses"], parts[0]["poses"])
+        assert int(part["nobs"]) == len(sc["obs_cam"])
+    assert abs(float(parts[0]["cost0"]) - rep0["cost0"]) <= 1e-12 * rep0["cost0"]
+    assert abs(float(parts[0]["cost"]) - rep0["cost"]) <= 1e-8 * rep0["cost"]
+    X = np.concatenate([part["points"] for part in parts])
+    assert [int(p["lo"]) for p in parts[1:]] == [int(p["hi"]) for p in parts[:-1]]
+    np.testing.assert_allclose(parts[0]["poses"], P0, rtol=0, atol=atol)
+    np.testing.assert_allclose(X, X0, rtol=0, atol=atol)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_ring_matches_single_gpu(world, tmp_path):
+    """The bench workload's shape (ring, 50 cameras, one-workgroup PCG) at 1/10 of its landmarks."""
+    sc = scenes.ring_scene(50, 2000, 10)
+    P0, X0, rep0 = single_gpu(sc, ftol=1e-12)
+    parts = run_ranks(world, "ring", tmp_path, ftol=1e-12)
+    check_against_single(parts, sc, P0, X0, rep0, atol=1e-6)
+
+
+def test_sharded_unstructured_scene_takes_the_union_of_block_patterns(tmp_path):
+    """Random visibility: the ranks see different camera pairs, so the pattern union matters."""
+    sc = scenes.noisy_scene(8, 400)
+    P0, X0, rep0 = single_gpu(sc, ftol=1e-12)
+    parts = run_ranks(2, "noisy", tmp_path, ftol=1e-12)
+    check_against_single(parts, sc, P0, X0, rep0, atol=1e-6)
+
+
+def test_sharded_direct_solver(tmp_path):
+    """Two ranks with the banded Cholesky (300 cameras in a ring): the factorisation runs replicated on the
+    all-reduced system."""
+    sc = scenes.ring_scene(300, 3000, 6)
+    P0, X0, rep0 = single_gpu(sc, ftol=1e-12)
+    parts = run_ranks(2, "ring_long", tmp_path, ftol=1e-12)
+    assert str(parts[0]["solver"]) == "banded_cholesky"
+    check_against_single(parts, sc, P0, X0, rep0, atol=1e-6)
+
+
+def test_sharded_multi_kernel_pcg(tmp_path, monkeypatch):
+    """Two ranks on the multi-kernel PCG path (camera systems too large for one workgroup): the ranks follow rank
+    0's convergence scalars and camera step (the two broadcasts of the path)."""
+    monkeypatch.setenv("BA_SMALL_SOLVE", "0")
+    sc = scenes.ring_scene(50, 2000, 10)
+    P0, X0, rep0 = single_gpu(sc, ftol=1e-12, pcg_tol=1e-6, linear_solver=1)
+    parts = run_ranks(2, "ring", tmp_path, ftol=1e-12, pcg_tol=1e-6, linear_solver=1)
+    assert str(parts[0]["solver"]) == "pcg"
+    check_against_single(parts, sc, P0, X0, rep0, atol=1e-6)
