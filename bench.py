@@ -95,7 +95,10 @@ def main():
     L = L1 * world
     scene = scenes.ring_scene(C, L, d, seed=0)
     extra = {} if args.lm_check_every is None else {"lm_check_every": args.lm_check_every}
-    solver = _native.Solver(device=local_rank, profile_kernels=0, **extra)
+    # BA_BENCH_DEVICE: rehearsal knob only (several ranks on the one-GPU test box, with BA_RCCL_LIBRARY naming
+    # tests/fake_rccl/librccl.so); the driver's runs use one GPU per rank
+    device = int(os.environ.get("BA_BENCH_DEVICE", local_rank))
+    solver = _native.Solver(device=device, profile_kernels=0, **extra)
     if dist is not None:
         uid = [_native.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)

@@ -1,5 +1,5 @@
 """One rank of tests/test_gpu_two_ranks.py (not collected by pytest).  Started with the test stand-in for
-librccl.so first on LD_LIBRARY_PATH, so that several ranks can share GPU 0; does exactly what bench.py does at
+librccl.so named in BA_RCCL_LIBRARY, so that several ranks can share GPU 0; does exactly what bench.py does at
 N > 1: join the communicator, take its landmark shard, solve, and write its part of the estimate."""
 
 import os

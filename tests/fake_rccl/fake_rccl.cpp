@@ -7,7 +7,7 @@
 // RCCL's (stream-ordered), never weaker, so a schedule that is right here is right there as far as data flow goes.
 // Every wait has a deadline: a rank that does not show up aborts the process instead of hanging the box.
 //
-// Only tests/test_gpu_two_ranks.py loads this (through LD_LIBRARY_PATH of the rank processes it starts).
+// Only tests/test_gpu_two_ranks.py loads this (through BA_RCCL_LIBRARY in the rank processes it starts).
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>

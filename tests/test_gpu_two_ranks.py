@@ -1,7 +1,7 @@
 """The landmark-sharded solve with MORE than one rank, on the one-GPU test box.
 
 RCCL refuses two ranks on one device, so the rank processes are started with tests/fake_rccl (a test-only stand-in
-for librccl.so that does each collective through host shared memory) first on LD_LIBRARY_PATH.  What runs is the
+for librccl.so that does each collective through host shared memory) named in BA_RCCL_LIBRARY.  What runs is the
 library's real multi-rank code: the union of the ranks' block patterns, the all-reduce of [S | rhs | U, gc] in every
 LM iteration, the folded statistics, the device-side LM control on every rank.  The sharded estimate must agree with
 the single-GPU solve of the same scene."""
@@ -25,7 +25,7 @@ SHIM_DIR = os.path.join(HERE, "fake_rccl")
 def run_ranks(world, scene_name, tmp_path, **options):
     assert os.path.exists(os.path.join(SHIM_DIR, "librccl.so")), "run __graft_entry__.build() first"
     env = dict(os.environ)
-    env["LD_LIBRARY_PATH"] = SHIM_DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    env["BA_RCCL_LIBRARY"] = os.path.join(SHIM_DIR, "librccl.so")
     args = [f"{k}={v}" for k, v in options.items()]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_two_rank_worker.py"), str(r), str(world),
                                str(tmp_path), scene_name] + args, env=env, stdout=subprocess.PIPE,

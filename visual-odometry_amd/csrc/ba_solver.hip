@@ -48,7 +48,10 @@ Rccl* rccl_load() {
   static bool tried = false;
   if (tried) return r.lib ? &r : nullptr;
   tried = true;
-  void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  // BA_RCCL_LIBRARY names the library file outright (a site build of RCCL; the test stand-in of tests/fake_rccl)
+  const char* named = getenv("BA_RCCL_LIBRARY");
+  void* lib = named && *named ? dlopen(named, RTLD_NOW | RTLD_LOCAL) : dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (named && *named && !lib) return nullptr;  // a named library that does not load is an error, not a cue to look elsewhere
   if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
   if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
   if (!lib) return nullptr;
