@@ -102,3 +102,11 @@ def test_sharded_multi_kernel_pcg(tmp_path, monkeypatch):
     parts = run_ranks(2, "ring", tmp_path, ftol=1e-12, pcg_tol=1e-6, linear_solver=1)
     assert str(parts[0]["solver"]) == "pcg"
     check_against_single(parts, sc, P0, X0, rep0, atol=1e-6)
+
+
+def test_sharded_robust_loss(tmp_path):
+    """Two ranks with a Huber loss: the robust cost and the IRLS weights are per observation, hence per shard."""
+    sc = scenes.ring_scene(50, 2000, 10)
+    P0, X0, rep0 = single_gpu(sc, ftol=1e-12, loss=2, f_scale=1.0)
+    parts = run_ranks(2, "ring", tmp_path, ftol=1e-12, loss=2, f_scale=1.0)
+    check_against_single(parts, sc, P0, X0, rep0, atol=1e-6)
