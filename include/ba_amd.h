@@ -187,6 +187,28 @@ int ba_solve_batched(ba_handle* h, int32_t n_problems, const int32_t* cam_off, c
 int ba_evaluate(ba_handle* h, const double* poses, const double* points, double* residuals, double* cost,
                 int32_t* n_behind);
 
+/* Residuals and cost WITHOUT any allocation.  No counterpart in the reference (which allocates freely: every call
+ * of BundleAdjustment.residual_function builds new arrays, bundle_adjustment.py:41-87); this entry point is for
+ * callers that cannot call hipMalloc: code under HIP graph capture, tight serving loops that evaluate the residual
+ * as a callback, harnesses that forbid allocation.  It is ba_evaluate without a handle and without ba_set_problem:
+ * the same residual arithmetic on the observations in the caller's order, camera 0 being the fixed pose
+ * (its quaternion is normalised only if off by more than 1e-6, the others always, as in ba_evaluate), plain
+ * squared loss.  Everything it needs on the device (staged copies of the inputs, the residuals, per-block partial
+ * sums) lives in a static device array of about 6.9 MB that every GPU used by the library holds until the process
+ * ends; it calls no hipMalloc / hipFree and creates no stream (default stream, blocking copies).
+ * Limits: n_cams <= BA_STATIC_MAX_CAMS, n_pts <= BA_STATIC_MAX_PTS, n_obs <= BA_STATIC_MAX_OBS; beyond them it
+ * returns BA_ERR_INVALID and the caller uses ba_evaluate.  device = HIP ordinal, -1 = current device.
+ * err (may be NULL) receives the message for a non-zero status (there is no handle to ask).
+ * Calls on one GPU share that GPU's array: the library serialises them with a process-wide lock, so calls from
+ * several threads are safe but do not overlap; calls from different PROCESSES use different copies. */
+#define BA_STATIC_MAX_OBS 131072
+#define BA_STATIC_MAX_CAMS 1024
+#define BA_STATIC_MAX_PTS 65536
+int ba_evaluate_static(int32_t device, int32_t n_cams, int32_t n_pts, int32_t n_obs, const int32_t* obs_cam,
+                       const int32_t* obs_pt, const double* obs_uv, const double* intr, const double* poses,
+                       const double* points, double* residuals, double* cost, int32_t* n_behind, char* err,
+                       int32_t err_len);
+
 /* Multi-view triangulation of every landmark of the current problem from KNOWN poses: the step on the
  * input side of the path (initial points for ba_solve).  For two views this is what
  * VisualOdometry.triangulate_points computes (visual_odometry.py:508-570: cv2.triangulatePoints, the linear

@@ -492,6 +492,61 @@ __global__ __launch_bounds__(256) void k_cost(DeviceProblem d,
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_residuals_static / k_reduce_static: the residual pass of ba_evaluate for ba_evaluate_static, the entry
+// point that allocates nothing.  Same arithmetic as k_cost (quat_to_R, to_camera, reproject); everything
+// beyond the caller's data lives in the library's static scratch array, whose regions arrive as kernel
+// arguments.  Observations are taken in the caller's order (no track sort), the residuals go out in that
+// order, and every block leaves its three partial sums (cost, z <= 0 count, z == 0 count) in its own slot:
+// no atomics, so the second kernel folds them in a fixed order and the cost is bitwise reproducible.
+// Algorithmic bytes: 24 B/obs read + 16 B/obs written (+ cached P, pose).
+__global__ __launch_bounds__(256) void k_residuals_static(Intrinsics K, int n, const int* __restrict__ cam,
+                                                          const int* __restrict__ pt, const double* __restrict__ uv,
+                                                          const double* __restrict__ poses,
+                                                          const double* __restrict__ pts, double* __restrict__ res,
+                                                          double* __restrict__ partial) {
+  __shared__ double red[4];
+  double cost = 0.0;
+  int nbehind = 0, nzero = 0;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < n) {
+    const int c = cam[k];
+    const long j = pt[k];
+    const double P[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
+    double R[9], X[3], r0, r1;
+    quat_to_R(poses + 7 * c + 3, R);
+    to_camera(R, poses + 7 * c, P, X);
+    reproject(K, X, uv[2 * k], uv[2 * k + 1], r0, r1);
+    nbehind = X[2] <= 0.0;
+    nzero = X[2] == 0.0;
+    cost = 0.5 * (r0 * r0 + r1 * r1);
+    res[2 * k] = r0;
+    res[2 * k + 1] = r1;
+  }
+  const double bc = block_sum_256(cost, red);
+  const double bb = block_sum_256((double)nbehind, red);
+  const double bz = block_sum_256((double)nzero, red);
+  if (threadIdx.x == 0) {
+    partial[3 * blockIdx.x] = bc;
+    partial[3 * blockIdx.x + 1] = bb;
+    partial[3 * blockIdx.x + 2] = bz;
+  }
+}
+
+// one block: out[0..2] = column sums of partial[nblocks][3], summed in block order
+__global__ __launch_bounds__(256) void k_reduce_static(const double* __restrict__ partial, int nblocks,
+                                                       double* __restrict__ out) {
+  __shared__ double red[4];
+  double a[3] = {0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < nblocks; b += 256) {
+    a[0] += partial[3 * b]; a[1] += partial[3 * b + 1]; a[2] += partial[3 * b + 2];
+  }
+  for (int i = 0; i < 3; ++i) {
+    const double s = block_sum_256(a[i], red);
+    if (threadIdx.x == 0) out[i] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_triangulate: multi-view triangulation of every landmark track from known poses -- the step on the
 // input side of the path.  One lane per landmark (the eigen-solve dominates: spreading
 // a track over G lanes repeats it G times and was 2-4x slower).

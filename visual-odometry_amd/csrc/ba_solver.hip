@@ -16,6 +16,7 @@
 #include <numeric>
 #include <string>
 #include <limits>
+#include <mutex>
 #include <vector>
 
 #include <dlfcn.h>
@@ -65,6 +66,35 @@ Rccl* rccl_load() {
   return &r;
 }
 
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------- static scratch
+// ba_evaluate_static allocates nothing: everything it needs on the device beyond the caller's own arrays
+// (staged inputs, the residuals before they are copied out, per-block partial sums) lives in this file-scope
+// device array.  Every GPU the library runs on holds its own copy at its own address until the process ends;
+// host code never uses the array's name as an address, only the pointer hipGetSymbolAddress returned for
+// the device (kept per device in static_scratch_ptr).  Regions, in doubles:
+//   [partial 3 * blocks | out 4 | poses 7 * MAX_CAMS | points 3 * MAX_PTS | uv 2 * MAX_OBS | res 2 * MAX_OBS |
+//    cam (int32) MAX_OBS / 2 | pt (int32) MAX_OBS / 2]
+namespace {
+constexpr long ST_MAX_OBS = BA_STATIC_MAX_OBS, ST_MAX_CAMS = BA_STATIC_MAX_CAMS, ST_MAX_PTS = BA_STATIC_MAX_PTS;
+constexpr long ST_BLOCKS = (ST_MAX_OBS + 255) / 256;
+constexpr long ST_OFF_PARTIAL = 0;
+constexpr long ST_OFF_OUT = ST_OFF_PARTIAL + 3 * ST_BLOCKS;
+constexpr long ST_OFF_POSES = ST_OFF_OUT + 4;
+constexpr long ST_OFF_PTS = ST_OFF_POSES + 7 * ST_MAX_CAMS;
+constexpr long ST_OFF_UV = ST_OFF_PTS + 3 * ST_MAX_PTS;
+constexpr long ST_OFF_RES = ST_OFF_UV + 2 * ST_MAX_OBS;
+constexpr long ST_OFF_CAM = ST_OFF_RES + 2 * ST_MAX_OBS;
+constexpr long ST_OFF_PT = ST_OFF_CAM + ST_MAX_OBS / 2;
+constexpr long ST_DOUBLES = ST_OFF_PT + ST_MAX_OBS / 2;
+static_assert(ST_MAX_OBS % 2 == 0 && ST_OFF_POSES % 2 == 0, "regions stay 16-byte aligned");
+constexpr int ST_MAX_DEVICES = 64;
+}  // namespace
+static __device__ __align__(256) double scratch[ST_DOUBLES];
+namespace {
+double* static_scratch_ptr[ST_MAX_DEVICES] = {};  // per device: the address of that GPU's copy of `scratch`
+std::mutex static_scratch_mutex;                  // calls that overlap on one GPU would race on its array: serialised
 }  // namespace
 
 struct ba_handle {
@@ -1702,6 +1732,99 @@ int ba_debug_linearization(ba_handle* h, const double* poses, const double* poin
       for (int e = 0; e < 3; ++e)
         dp[3 * (size_t)h->lm_internal_to_user[j] + e] = j < h->L_obs ? a[3 * (size_t)j + e] - b[3 * (size_t)j + e] : 0.0;
   }
+  return BA_OK;
+}
+
+int ba_evaluate_static(int32_t device, int32_t C, int32_t L, int32_t n, const int32_t* obs_cam, const int32_t* obs_pt,
+                       const double* obs_uv, const double* intr, const double* poses, const double* points,
+                       double* residuals, double* cost, int32_t* n_behind, char* err, int32_t err_len) {
+  auto bad = [&](int code, const char* fmt, ...) {
+    if (err && err_len > 0) {
+      va_list ap;
+      va_start(ap, fmt);
+      vsnprintf(err, (size_t)err_len, fmt, ap);
+      va_end(ap);
+    }
+    return code;
+  };
+  if (!obs_cam || !obs_pt || !obs_uv || !intr || !poses || !points)
+    return bad(BA_ERR_INVALID, "evaluate_static: null pointer");
+  if (C <= 0 || L <= 0 || n <= 0) return bad(BA_ERR_INVALID, "evaluate_static: empty problem (C=%d L=%d n=%d)", C, L, n);
+  if (C > ST_MAX_CAMS || L > ST_MAX_PTS || n > ST_MAX_OBS)
+    return bad(BA_ERR_INVALID,
+               "evaluate_static: C=%d L=%d n=%d exceeds the static scratch (at most %ld cameras, %ld landmarks, %ld "
+               "observations): use ba_evaluate", C, L, n, ST_MAX_CAMS, ST_MAX_PTS, ST_MAX_OBS);
+  for (int i = 0; i < 7; ++i)
+    if (!std::isfinite(intr[i])) return bad(BA_ERR_INVALID, "intrinsics[%d] is not finite", i);
+  if (!(intr[0] > 0) || !(intr[1] > 0)) return bad(BA_ERR_INVALID, "focal lengths must be positive");
+  for (int k = 0; k < n; ++k) {
+    if (obs_cam[k] < 0 || obs_cam[k] >= C) return bad(BA_ERR_INVALID, "obs_cam[%d]=%d out of range", k, obs_cam[k]);
+    if (obs_pt[k] < 0 || obs_pt[k] >= L) return bad(BA_ERR_INVALID, "obs_pt[%d]=%d out of range", k, obs_pt[k]);
+    if (!std::isfinite(obs_uv[2 * (size_t)k]) || !std::isfinite(obs_uv[2 * (size_t)k + 1]))
+      return bad(BA_ERR_INVALID, "observation %d is not finite", k);
+  }
+  for (size_t i = 0; i < (size_t)3 * L; ++i)
+    if (!std::isfinite(points[i])) return bad(BA_ERR_INVALID, "landmark %d has a non-finite coordinate", (int)(i / 3));
+  // poses exactly as stage_state prepares them for ba_evaluate: pose 0 is the fixed one
+  double sp[7 * ST_MAX_CAMS];
+  for (int c = 0; c < C; ++c) {
+    const double* p = poses + 7 * c;
+    for (int i = 0; i < 7; ++i)
+      if (!std::isfinite(p[i])) return bad(BA_ERR_INVALID, "pose %d has a non-finite entry", c);
+    const double nq = std::sqrt(p[3] * p[3] + p[4] * p[4] + p[5] * p[5] + p[6] * p[6]);
+    if (nq == 0.0) return bad(BA_ERR_INVALID, "pose %d has a zero quaternion", c);
+    const bool renorm = c != 0 || std::fabs(nq - 1.0) > 1e-6;
+    for (int i = 0; i < 3; ++i) sp[7 * c + i] = p[i];
+    for (int i = 3; i < 7; ++i) sp[7 * c + i] = renorm ? p[i] / nq : p[i];
+  }
+#define ST_TRY(expr)                                                                                      \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess) return bad(BA_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));       \
+  } while (0)
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return bad(BA_ERR_DEVICE, "no HIP device (there is no CPU fallback)");
+  if (device < 0) ST_TRY(hipGetDevice(&device));
+  if (device >= ndev || device >= ST_MAX_DEVICES) return bad(BA_ERR_INVALID, "device %d does not exist", device);
+  std::lock_guard<std::mutex> lock(static_scratch_mutex);
+  ST_TRY(hipSetDevice(device));
+  if (!static_scratch_ptr[device]) {  // once per device, with that device current: the address of ITS copy
+    double* ptr = nullptr;
+    ST_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return bad(BA_ERR_DEVICE, "hipGetSymbolAddress returned a null address for the static scratch");
+    static_scratch_ptr[device] = ptr;
+  }
+  double* const base = static_scratch_ptr[device];
+  double* d_partial = base + ST_OFF_PARTIAL;
+  double* d_out = base + ST_OFF_OUT;
+  double* d_poses = base + ST_OFF_POSES;
+  double* d_pts = base + ST_OFF_PTS;
+  double* d_uv = base + ST_OFF_UV;
+  double* d_res = base + ST_OFF_RES;
+  int* d_cam = reinterpret_cast<int*>(base + ST_OFF_CAM);
+  int* d_pt = reinterpret_cast<int*>(base + ST_OFF_PT);
+  // the array keeps the last call's contents: every region read below is overwritten first, for exactly the
+  // extent this call uses (partial sums: one slot per block of THIS launch; nothing needs a clear)
+  ST_TRY(hipMemcpy(d_poses, sp, (size_t)7 * C * sizeof(double), hipMemcpyHostToDevice));
+  ST_TRY(hipMemcpy(d_pts, points, (size_t)3 * L * sizeof(double), hipMemcpyHostToDevice));
+  ST_TRY(hipMemcpy(d_uv, obs_uv, (size_t)2 * n * sizeof(double), hipMemcpyHostToDevice));
+  ST_TRY(hipMemcpy(d_cam, obs_cam, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+  ST_TRY(hipMemcpy(d_pt, obs_pt, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+  const Intrinsics K{intr[0], intr[1], intr[2], intr[3], intr[4], intr[5], intr[6],
+                     (intr[4] != 0.0 || intr[5] != 0.0 || intr[6] != 0.0) ? 1 : 0};
+  const int blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(k_residuals_static, dim3(blocks), dim3(256), 0, nullptr, K, (int)n, (const int*)d_cam,
+                     (const int*)d_pt, (const double*)d_uv, (const double*)d_poses, (const double*)d_pts, d_res, d_partial);
+  ST_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_reduce_static, dim3(1), dim3(256), 0, nullptr, (const double*)d_partial, blocks, d_out);
+  ST_TRY(hipGetLastError());
+  double out[3] = {0.0, 0.0, 0.0};
+  ST_TRY(hipMemcpy(out, d_out, sizeof out, hipMemcpyDeviceToHost));
+  if (residuals) ST_TRY(hipMemcpy(residuals, d_res, (size_t)2 * n * sizeof(double), hipMemcpyDeviceToHost));
+#undef ST_TRY
+  if (cost) *cost = out[0];
+  if (n_behind) *n_behind = (int32_t)out[1];
+  if (out[2] > 0.0) return bad(BA_ERR_NUMERICAL, "cannot project points with zero Z coordinates (division by zero)");
   return BA_OK;
 }
 

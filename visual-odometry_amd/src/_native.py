@@ -72,6 +72,8 @@ _SIGNATURES = {
     "ba_download_estimate": (C.c_int, [_P, _D, _D]),
     "ba_solve_batched": (C.c_int, [_P, C.c_int32, _I, _I, _I, _I, _I, _D, _D, _D, _D, _D, _D, C.POINTER(BaReport)]),
     "ba_evaluate": (C.c_int, [_P, _D, _D, _D, _D, _I]),
+    "ba_evaluate_static": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _I, _I, _D, _D, _D, _D, _D, _D, _I,
+                                     C.c_char_p, C.c_int32]),
     "ba_triangulate": (C.c_int, [_P, _D, C.c_int32, C.c_double, _D, _D, C.POINTER(C.c_uint8)]),
     "ba_jacobian_blocks": (C.c_int, [_P, _D, _D, _D, _D]),
     "ba_debug_linearization": (C.c_int, [_P, _D, _D, C.c_double] + [_D] * 9),
@@ -123,6 +125,43 @@ def _f64(a, shape=None) -> np.ndarray:
     if shape is not None and a.shape != shape:
         raise ValidationError(f"expected array of shape {shape}, got {a.shape}")
     return a
+
+
+STATIC_MAX_OBS, STATIC_MAX_CAMS, STATIC_MAX_PTS = 131072, 1024, 65536  # BA_STATIC_MAX_* (include/ba_amd.h)
+
+
+def fits_static(n_cams: int, n_pts: int, n_obs: int) -> bool:
+    return 0 < n_cams <= STATIC_MAX_CAMS and 0 < n_pts <= STATIC_MAX_PTS and 0 < n_obs <= STATIC_MAX_OBS
+
+
+def evaluate_static(n_cams, n_pts, obs_cam, obs_pt, obs_uv, intr, poses, points, want_residuals=True, device=-1):
+    """ba_evaluate_static: residuals, cost and behind-camera count without a handle and without any
+    allocation on the device (static scratch inside the library; sizes up to STATIC_MAX_*)."""
+    lib = load_library()
+    obs_cam = np.ascontiguousarray(obs_cam, dtype=np.int32)
+    obs_pt = np.ascontiguousarray(obs_pt, dtype=np.int32)
+    n = len(obs_cam)
+    if obs_pt.shape != (n,):
+        raise ValidationError("obs_cam and obs_pt must have the same length")
+    obs_uv = _f64(obs_uv, (n, 2))
+    intr = _f64(intr, (7,))
+    poses = _f64(poses, (n_cams, 7))
+    points = _f64(points, (n_pts, 3))
+    res = np.empty(2 * n) if want_residuals else None
+    cost = C.c_double()
+    nb = C.c_int32()
+    err = C.create_string_buffer(512)
+    rc = lib.ba_evaluate_static(int(device), int(n_cams), int(n_pts), n, obs_cam.ctypes.data_as(_I),
+                                obs_pt.ctypes.data_as(_I), _dptr(obs_uv), _dptr(intr), _dptr(poses), _dptr(points),
+                                _dptr(res), C.byref(cost), C.byref(nb), err, 512)
+    if rc != 0:
+        msg = err.value.decode("utf-8", "replace")
+        if rc == 1:
+            raise ValidationError(msg)
+        if rc == 2:
+            raise ProcessingError(msg)
+        raise RuntimeError(f"libba_amd status {rc}: {msg}")
+    return res, cost.value, nb.value
 
 
 class Solver:
