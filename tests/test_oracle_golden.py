@@ -204,3 +204,22 @@ def test_lm_oracle_robust_minimum(golden, loss):
         assert abs(rep.cost - pol) <= 1e-6 * pol, (rep.cost, pol)
     else:
         assert rep.cost <= pol * (1 + 1e-6), (rep.cost, pol)
+
+
+@pytest.mark.parametrize("name", ["ring_50x20000", "ring_1000x200000"])
+def test_full_size_residual_matches_reference(golden, name):
+    """BASELINE configs[1] / configs[2] at full size: the oracle's vectorised residual at x0 against every stride-th
+    value that the reference's own residual_function produced there (fixture: oracle/make_golden.py), 1e-9 px; and the
+    recorded scalars are what SURVEY.md section 6 measured with the reference (cost to 1e-7 relative, nfev)."""
+    import scenes
+    g = golden(name)
+    C, L, d = (int(v) for v in g["ring_params"])
+    st = int(g["stride"])
+    sc = scenes.ring_scene(C, L, d)
+    r = orc.residual_packed(sc["x0"], sc["pose0"], C - 1, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+    np.testing.assert_allclose(r[::st], g["residual_at_x0_s"], rtol=0, atol=1e-9)
+    assert float(g["restated_residual_max_diff"]) <= 1e-9
+    survey = {"ring_50x20000": (42593.36855718, 6), "ring_1000x200000": (173983.456159, 17)}[name]
+    assert abs(float(g["ref_cost"]) - survey[0]) <= 1e-7 * survey[0] and int(g["ref_nfev"]) == survey[1]
+    assert int(g["ref_status"]) == 2 and int(g["polished_status"]) in (1, 2, 3)
+    assert float(g["polished_cost"]) < float(g["ref_cost"])
