@@ -32,7 +32,8 @@ extern "C" {
 #endif
 
 #define BA_AMD_VERSION 100 /* 0.1.0 */
-#define BA_HISTORY 128     /* per-iteration history entries kept in ba_report */
+#define BA_HISTORY 128     /* per-iteration history entries kept in ba_report: the first BA_HISTORY - 1 iterations and,
+                              in the last entry, the most recent one (a solve may run longer; n_history stops at 128) */
 
 typedef enum {
   BA_OK = 0,
@@ -74,7 +75,7 @@ typedef enum {
  * tighter (ftol = scipy's own default) so that the converged cost is at or below the reference's
  * (SURVEY.md section 7). */
 typedef struct {
-  int32_t max_iters;        /* LM iterations (linearisations), default 200 */
+  int32_t max_iters;        /* LM iterations, accepted + rejected; default 2000 (the reference's max_nfev=2000) */
   double ftol;              /* stop when an accepted step lowers the cost by <= ftol * cost; 1e-8 */
   double xtol;              /* stop when |step| <= xtol * (xtol + |x|); 1e-12 */
   double gtol;              /* stop when |J^T r|_inf <= gtol; 1e-10 */
@@ -83,7 +84,10 @@ typedef struct {
   double lambda_max;        /* 1e12 */
   double min_diag;          /* floor of the Marquardt diagonal, 1e-12 */
   double accept_ratio;      /* accept a step when actual/predicted decrease > this, 1e-4 */
-  int32_t guard_cheirality; /* reject a step that moves more observations behind their camera, 1 */
+  int32_t guard_cheirality; /* 1 (default): a landmark step that would carry the landmark through the principal plane of one
+                               of its cameras is shortened (depths keep >= 1/10 of their value), and a whole step that still
+                               moves more observations behind their camera is rejected; 0: neither (the reference has no
+                               cheirality test, camera.py:101-165) */
   int32_t linear_solver;    /* ba_linear_solver, default BA_SOLVER_AUTO */
   double pcg_tol;           /* relative residual (M^-1 norm) at which block-Jacobi PCG stops, 3e-2 */
   int32_t pcg_max_iter;     /* 1000 */
@@ -108,6 +112,10 @@ typedef struct {
   int32_t status;      /* ba_stop */
   int32_t pcg_iters;   /* total PCG iterations */
   int32_t nobs;
+  int32_t bad_pivots;       /* non-positive pivots / non-SPD blocks met by the linear solves (each such step was rejected) */
+  int32_t guard_rejections; /* steps refused because they put more observations behind their camera */
+  int32_t shortened_steps;  /* landmark steps shortened so that the landmark stays in front of its cameras (summed over iterations) */
+  int32_t reserved_;
   double solve_ms;     /* wall time inside the solve, device-synchronised */
   double setup_ms;     /* wall time of the last ba_set_problem (index build + upload) */
   int32_t n_history;
@@ -183,7 +191,10 @@ int ba_solve_batched(ba_handle* h, int32_t n_problems, const int32_t* cam_off, c
  * BundleAdjustment.residual_function (bundle_adjustment.py:20-87).  n_behind (may be NULL) receives
  * the number of observations with z <= 0.  Returns BA_ERR_NUMERICAL if some z == 0, as
  * PinHoleCamera.project raises ProcessingError there (camera.py:129-132).  The residuals are always the
- * plain re-projection errors; *cost is the robust cost when opt.loss is set (as scipy's result.cost). */
+ * plain re-projection errors; *cost is the robust cost when opt.loss is set (as scipy's result.cost).
+ * Side effect: the point is staged in the handle's trial buffers, so the estimate of an earlier ba_solve_resident is
+ * gone (ba_download_estimate then returns BA_ERR_STATE until the next solve); the same holds for
+ * ba_jacobian_blocks, ba_debug_linearization and ba_triangulate. */
 int ba_evaluate(ba_handle* h, const double* poses, const double* points, double* residuals, double* cost,
                 int32_t* n_behind);
 
@@ -257,10 +268,18 @@ int ba_set_kernel_timing(ba_handle* h, int32_t on);
  * ba_set_problem.  Afterwards each rank describes ITS shard to ba_set_problem: all C cameras, its own
  * landmarks and their observations (obs_pt indexes the local landmark array).  Poses are replicated
  * (every rank passes and receives all of them); points are rank-local.  ba_solve* then runs the same
- * iteration on every rank with one RCCL all-reduce of [partial S | reduced rhs | U, gc] per
- * linear solve, a broadcast of the camera step and one all-reduce of the scalar statistics; report
- * fields are global.  ba_evaluate / ba_jacobian_blocks stay rank-local.  With world == 1 the same code
- * path runs with single-rank collectives. */
+ * iteration on every rank with one RCCL all-reduce of [partial S | reduced rhs | U, gc] per linear solve and one
+ * all-reduce of the scalar statistics; report fields are global.  There is no broadcast of the camera step: every rank
+ * solves the same all-reduced system with a solver whose summation order is fixed, which keeps the replicated poses
+ * bit-identical PROVIDED the all-reduce hands every rank the same bits (true of RCCL's ring and tree algorithms, where
+ * every rank receives the one reduced buffer; checked with the test stand-in for librccl, not yet on a multi-GPU node).
+ * Only the multi-kernel PCG, which reduces with atomics, ships rank 0's step.
+ * Every rank needs at least one landmark and one observation.  ba_set_problem, ba_upload_guess and ba_solve* agree on
+ * a status before their first data collective: if any rank's arguments are bad (an empty shard, an index out of range,
+ * a non-finite guess) EVERY rank returns that status and none is left waiting inside RCCL.  ba_evaluate /
+ * ba_jacobian_blocks / ba_triangulate stay rank-local; ba_solve_batched refuses a handle with a communicator (windows
+ * are independent: give each rank its own plain handle).  With world == 1 the same code path runs with single-rank
+ * collectives. */
 int ba_comm_unique_id(char* id128);
 int ba_comm_init(ba_handle* h, int32_t rank, int32_t world, const char* id128);
 

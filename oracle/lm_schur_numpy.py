@@ -223,6 +223,24 @@ def back_substitute(dc, Vi, W, gp, obs_cam, obs_pt, L):
     return -np.einsum("lij,lj->li", Vi, t)
 
 
+GUARD_KEEP = 0.1  # == GUARD_KEEP of csrc/ba_kernels.h
+
+
+def guard_landmark_steps(poses, points, dp, obs_cam, obs_pt):
+    """The per-landmark cheirality guard of k_backsub: a landmark step that would take the depth of the landmark in one
+    of its cameras (at the CURRENT poses) below GUARD_KEEP times its value is shortened to the point where it does.
+    Returns the shortened steps and how many were shortened."""
+    r3 = quat_to_rot(poses[:, 3:7])[:, :, 2][obs_cam]  # the cameras' optical axes in the world frame
+    z0 = np.sum((points[obs_pt] - poses[obs_cam, :3]) * r3, axis=1)
+    dz = np.sum(dp[obs_pt] * r3, axis=1)
+    hit = (z0 > 0) & (z0 + dz < GUARD_KEEP * z0)
+    a = np.ones(len(z0))
+    a[hit] = (1.0 - GUARD_KEEP) * z0[hit] / -dz[hit]
+    alpha = np.ones(len(points))
+    np.minimum.at(alpha, obs_pt, a)
+    return dp * alpha[:, None], int(np.sum(alpha < 1.0))
+
+
 def block_jacobi_pcg(S, b, tol, max_iter, C):
     """Preconditioned CG on S x = b with 6x6 block-Jacobi; stops on sqrt(r^T z) <= tol * sqrt(r0^T z0)."""
     Sd = S.toarray() if sp.issparse(S) and S.shape[0] <= 6000 else None
@@ -264,7 +282,8 @@ class LMOptions:
     lambda_max: float = 1e12
     min_diag: float = 1e-12
     accept_ratio: float = 1e-4
-    guard_cheirality: bool = True  # reject a step that puts more observations behind their camera
+    guard_cheirality: bool = True  # shorten landmark steps that cross a camera's principal plane; reject a step that
+    #                                still puts more observations behind their camera
     linear_solver: str = "direct"  # "direct" | "pcg"
     pcg_tol: float = 1e-2
     pcg_max_iter: int = 500
@@ -283,6 +302,8 @@ class LMReport:
     lambdas: List[float] = field(default_factory=list)
     pcg_iters: List[int] = field(default_factory=list)
     grad_inf: float = 0.0
+    shortened_steps: int = 0  # landmark steps shortened by the per-landmark cheirality guard, summed over iterations
+    guard_rejections: int = 0
 
 
 def lm_solve(poses, points, obs_cam, obs_pt, obs_uv, intr, free: Optional[np.ndarray] = None,
@@ -326,6 +347,9 @@ def lm_solve(poses, points, obs_cam, obs_pt, obs_uv, intr, free: Optional[np.nda
             dcv = np.linalg.solve(S, -rhs)
         dc = dcv.reshape(C, 6) * free[:, None]
         dp = back_substitute(dc, Vi, W, gp, obs_cam, obs_pt, L)
+        if opt.guard_cheirality:  # the model decrease below is that of the step actually taken
+            dp, n_short = guard_landmark_steps(poses, points, dp, obs_cam, obs_pt)
+            rep.shortened_steps += n_short
         # predicted decrease of 0.5|r + J d|^2: -(g.d) - 0.5 d^T H d, from the blocks
         gd = float(np.sum(gc * dc) + np.sum(gp * dp))
         Wdp = np.einsum("nij,nj->ni", W, dp[obs_pt])
@@ -339,6 +363,7 @@ def lm_solve(poses, points, obs_cam, obs_pt, obs_uv, intr, free: Optional[np.nda
         rho = (cost - cost_t) / pred if pred > 0 else -1.0
         if opt.guard_cheirality and nbehind_t > nbehind:
             rho = -1.0
+            rep.guard_rejections += 1
         step_norm = np.sqrt(np.sum(dc * dc) + np.sum(dp * dp))
         x_norm = np.sqrt(np.sum(poses[:, :3] ** 2) + np.sum(points ** 2) + C)
         rep.lambdas.append(lam)

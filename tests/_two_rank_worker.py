@@ -37,6 +37,9 @@ def main():
         with open(uid_path, "rb") as fh:
             uid = fh.read()
 
+    fault = None
+    if ":" in scene_name:  # "<scene>:<fault>": rank 1 hands the library something invalid (tests of the status agreement)
+        scene_name, fault = scene_name.split(":")
     if scene_name == "ring":
         sc = scenes.ring_scene(50, 2000, 10)
     elif scene_name == "ring_long":
@@ -45,8 +48,29 @@ def main():
         sc = scenes.noisy_scene(8, 400)
     C = len(sc["poses_guess"])
     sh, _ = sharding.shard_arrays(sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["points_guess"], rank, world)
+    from src.validation_error import ValidationError
     with _native.Solver(device=0, **options) as s:
         s.comm_init(rank, world, uid)
+        if fault is not None:
+            stage, err = "none", ""
+            try:
+                if fault == "empty" and rank == 1:  # a shard without observations
+                    s.set_problem(C, len(sh["points"]), sh["obs_cam"][:0], sh["obs_pt"][:0], sh["obs_uv"][:0], sc["intr"])
+                else:
+                    s.set_problem(C, len(sh["points"]), sh["obs_cam"], sh["obs_pt"], sh["obs_uv"], sc["intr"])
+                stage = "set_problem"
+                pts = sh["points"].copy()
+                if fault == "nan" and rank == 1:
+                    pts[0, 1] = np.nan
+                s.solve(sc["poses_guess"], pts)
+                stage = "solve"
+            except ValidationError as e:
+                err = str(e)
+            # after the refused call every rank can still go through a good set_problem + solve together
+            s.set_problem(C, len(sh["points"]), sh["obs_cam"], sh["obs_pt"], sh["obs_uv"], sc["intr"])
+            _, _, rep = s.solve(sc["poses_guess"], sh["points"])
+            np.savez(os.path.join(workdir, f"rank{rank}.npz"), stage=stage, err=err, cost=rep["cost"])
+            return
         s.set_problem(C, len(sh["points"]), sh["obs_cam"], sh["obs_pt"], sh["obs_uv"], sc["intr"])
         P, X, rep = s.solve(sc["poses_guess"], sh["points"])
         kind = s.reduced_solver()

@@ -30,15 +30,15 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     # sizeof / offsetof printed by gcc for include/ba_amd.h (x86-64 SysV)
     assert ctypes.sizeof(_native.BaOptions) == 128 and _native.BaOptions.f_scale.offset == 120
-    assert ctypes.sizeof(_native.BaReport) == 3160
-    assert _native.BaReport.solve_ms.offset == 64 and _native.BaReport.cost_history.offset == 88
+    assert ctypes.sizeof(_native.BaReport) == 3176
+    assert _native.BaReport.solve_ms.offset == 80 and _native.BaReport.cost_history.offset == 104
 
 
 def test_defaults():
     lib = _native.load_library()
     o = _native.BaOptions()
     lib.ba_default_options(ctypes.byref(o))
-    assert o.max_iters == 200 and o.ftol == 1e-8 and o.lambda0 == 1e-4 and o.guard_cheirality == 1
+    assert o.max_iters == 2000 and o.ftol == 1e-8 and o.lambda0 == 1e-4 and o.guard_cheirality == 1
 
 
 def test_no_gpu_fails_loudly():

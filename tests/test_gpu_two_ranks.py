@@ -110,3 +110,18 @@ def test_sharded_robust_loss(tmp_path):
     P0, X0, rep0 = single_gpu(sc, ftol=1e-12, loss=2, f_scale=1.0)
     parts = run_ranks(2, "ring", tmp_path, ftol=1e-12, loss=2, f_scale=1.0)
     check_against_single(parts, sc, P0, X0, rep0, atol=1e-6)
+
+
+@pytest.mark.parametrize("fault,stage", [("empty", "none"), ("nan", "set_problem")])
+def test_invalid_input_on_one_rank_stops_every_rank(fault, stage, tmp_path):
+    """One rank hands the library a shard without observations / a guess with a NaN: every rank must get the
+    ValidationError (the ranks agree on a status before their data collectives) instead of rank 0 waiting forever
+    inside the all-reduce; afterwards the same handles go through a good set_problem + solve together."""
+    sc = scenes.ring_scene(50, 2000, 10)
+    _, _, rep0 = single_gpu(sc)
+    parts = run_ranks(2, "ring:" + fault, tmp_path)
+    for r, part in enumerate(parts):
+        assert str(part["stage"]) == stage, (r, str(part["stage"]), str(part["err"]))
+        assert str(part["err"]) != ""
+        assert abs(float(part["cost"]) - rep0["cost"]) <= 1e-8 * rep0["cost"]
+    assert "another rank" in str(parts[0]["err"])

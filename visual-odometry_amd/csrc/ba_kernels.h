@@ -20,6 +20,7 @@ enum ScalarSlot {
   SC_ZEROZ, SC_NONFINITE,
   // camera part of the step statistics: computed from replicated data, identical on every rank
   SC_GDOT_C, SC_DHD_C, SC_DNORM2_C, SC_XNORM2_C, SC_GINF_C,
+  SC_NSHORT,  // landmark steps shortened by the per-landmark cheirality guard of k_backsub
   SC_NSUM = 20,  // slots [0, SC_NSUM) are folded over the privatised copies (and over ranks)
   SC_RZ = 24, SC_RZ0, SC_PQ, SC_RZNEW, SC_DONE, SC_PCGIT,
   SC_COUNT = 32
@@ -31,6 +32,7 @@ constexpr int SCAL_SLABS = 64;
 #define SCAL_MINE(d) ((d).scal + (size_t)(blockIdx.x & (SCAL_SLABS - 1)) * SC_COUNT)
 
 constexpr int LM_HISTORY = 128;  // == BA_HISTORY (include/ba_amd.h)
+constexpr int LM_ACC_BITS = 16384;  // accept / reject of every iteration up to this many (1 bit each), for the kernel timers
 
 // Levenberg-Marquardt state that lives on the device: k_lm_decide takes the accept / reject decision
 // and updates the damping, so the host enqueues iterations without waiting for each one.
@@ -44,11 +46,14 @@ struct LmHead {
   int need_lin;  // the next iteration starts with a linearisation
   int done, status, error;  // error: 1 = z == 0 at the initial guess, 2 = non-finite initial cost
   int it, accepted, linearizations, pcg_total, n_hist;
+  int bad_pivots, guard_rejections;  // non-positive pivots / non-SPD blocks met by the solves; steps the cheirality guard refused
+  int shortened_steps, pad_;         // landmark steps that k_backsub shortened to keep the landmark in front of its cameras
 };
 struct LmCtrl : LmHead {
   double cost_hist[LM_HISTORY], lam_hist[LM_HISTORY], trial_hist[LM_HISTORY], rho_hist[LM_HISTORY],
       ginf_hist[LM_HISTORY], step_hist[LM_HISTORY];
   int pcg_hist[LM_HISTORY], acc_hist[LM_HISTORY];
+  unsigned acc_bits[LM_ACC_BITS / 32];  // bit i: iteration i + 1 accepted its step (the histories stop at LM_HISTORY)
 };
 static_assert(sizeof(LmHead) % 8 == 0, "LmHead must not have tail padding");
 // Copy of the head in pinned host memory: k_lm_decide stores it there and then raises `seq`, the host
@@ -445,6 +450,7 @@ __global__ __launch_bounds__(256) void k_init_solve(DeviceProblem d, const doubl
   }
   for (long t = t0; t < n_clear; t += stride) d.Ugc_slab[t] = 0.0;  // [U / gc slabs | scalar copies | S slabs]
   if (t0 == 0) *static_cast<LmHead*>(d.ctrl) = head;
+  if (t0 < LM_ACC_BITS / 32) d.ctrl->acc_bits[t0] = 0u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1818,15 +1824,17 @@ __global__ __launch_bounds__(256) void k_pose_update(DeviceProblem d, const doub
 // point part of the step statistics (g.d, d^T V d + 2 dc^T W dp, |d|^2, |x|^2).
 // Same group-per-track walk as k_linearize.  Algorithmic bytes: W 144 B/obs + 4 B/obs,
 // per landmark V 48 + gp 24 + P 24 read, P 24 written.
+constexpr double GUARD_KEEP = 0.1;  // a guarded landmark step keeps every depth above this fraction of its value
 template <int G>
 __global__ __launch_bounds__(256) void k_backsub(DeviceProblem d, double lam, double min_diag,
                                                  const double* __restrict__ pts, double* __restrict__ pts_t,
                                                  int lm_per_group, const double* __restrict__ poses,
-                                                 double* __restrict__ poses_t, int pose_blocks) {
+                                                 double* __restrict__ poses_t, int pose_blocks, int guard) {
   __shared__ double red[4];
   if (lam < 0.0) {
     const LmCtrl* c = d.ctrl;
     if (c->done) return;
+    guard = c->guard_cheirality;
     lam = c->lam;
     pts = d.pts_buf[c->sel];
     pts_t = d.pts_buf[c->sel ^ 1];
@@ -1844,6 +1852,7 @@ __global__ __launch_bounds__(256) void k_backsub(DeviceProblem d, double lam, do
   const long j1 = min((long)d.L_obs, j0 + lm_per_group);
   const long n = d.n;
   double gd = 0.0, dhd = 0.0, dn = 0.0, xn = 0.0;
+  int nshort = 0;
   for (long j = j0; j < j1; ++j) {
     const int kb = d.lm_ptr[j], ke = d.lm_ptr[j + 1];
     double t[3] = {0, 0, 0};
@@ -1860,17 +1869,38 @@ __global__ __launch_bounds__(256) void k_backsub(DeviceProblem d, double lam, do
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) t[c] = group_sum<G>(t[c]);
+    // every lane of the group forms the step (the operands are the same addresses for all of them: broadcast loads)
+    double v[6], vi[6], g[3], s[3], dp[3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = d.V[(long)i * d.L + j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g[i] = d.gp[(long)i * d.L + j];
+    damped_inv3(v, lam, min_diag, vi);
+    s[0] = g[0] + t[0]; s[1] = g[1] + t[1]; s[2] = g[2] + t[2];
+    sym3_mul(vi, s, dp);
+    dp[0] = -dp[0]; dp[1] = -dp[1]; dp[2] = -dp[2];
+    const double P[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
+    if (guard) {
+      // Cheirality, landmark by landmark: a step that would take the landmark through the principal plane of one of
+      // its cameras (depth z -> <= 0) is shortened so that no depth drops below a tenth of its value; the poses are
+      // the current ones (the cameras' own steps are small against such a jump; what still slips through is caught
+      // by the whole-step test in k_lm_decide).  The model decrease below is that of the step actually taken.
+      double alpha = 1.0;
+      for (int k = kb + lane; k < ke; k += G) {
+        const double* ps = poses + 7 * d.o_cam[k];
+        const double qw = ps[3], qx = ps[4], qy = ps[5], qz = ps[6];
+        const double r3[3] = {2 * qx * qz + 2 * qw * qy, 2 * qy * qz - 2 * qw * qx, 1 - 2 * qx * qx - 2 * qy * qy};
+        const double z0 = (P[0] - ps[0]) * r3[0] + (P[1] - ps[1]) * r3[1] + (P[2] - ps[2]) * r3[2];
+        const double dz = dp[0] * r3[0] + dp[1] * r3[1] + dp[2] * r3[2];
+        if (z0 > 0.0 && z0 + dz < GUARD_KEEP * z0) alpha = fmin(alpha, (1.0 - GUARD_KEEP) * z0 / -dz);
+      }
+      alpha = -group_max<G>(-alpha);
+      if (alpha < 1.0) {
+        dp[0] *= alpha; dp[1] *= alpha; dp[2] *= alpha;
+        nshort += (lane == 0);
+      }
+    }
     if (lane == 0) {
-      double v[6], vi[6], g[3], s[3], dp[3];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) v[i] = d.V[(long)i * d.L + j];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) g[i] = d.gp[(long)i * d.L + j];
-      damped_inv3(v, lam, min_diag, vi);
-      s[0] = g[0] + t[0]; s[1] = g[1] + t[1]; s[2] = g[2] + t[2];
-      sym3_mul(vi, s, dp);
-      dp[0] = -dp[0]; dp[1] = -dp[1]; dp[2] = -dp[2];
-      const double P[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
       pts_t[3 * j] = P[0] + dp[0]; pts_t[3 * j + 1] = P[1] + dp[1]; pts_t[3 * j + 2] = P[2] + dp[2];
       gd += g[0] * dp[0] + g[1] * dp[1] + g[2] * dp[2];
       const double vdp0 = v[0] * dp[0] + v[1] * dp[1] + v[2] * dp[2];
@@ -1882,13 +1912,14 @@ __global__ __launch_bounds__(256) void k_backsub(DeviceProblem d, double lam, do
     }
   }
   const double b0 = block_sum_256(gd, red), b1 = block_sum_256(dhd, red), b2 = block_sum_256(dn, red),
-               b3 = block_sum_256(xn, red);
+               b3 = block_sum_256(xn, red), b4 = block_sum_256((double)nshort, red);
   if (threadIdx.x == 0) {
     double* sc = SCAL_MINE(d);
     atomic_add_f64(&sc[SC_GDOT], b0);
     atomic_add_f64(&sc[SC_DHD], b1);
     atomic_add_f64(&sc[SC_DNORM2], b2);
     atomic_add_f64(&sc[SC_XNORM2], b3);
+    if (b4 != 0.0) atomic_add_f64(&sc[SC_NSHORT], b4);
   }
 }
 
@@ -2012,7 +2043,11 @@ __global__ __launch_bounds__(256) void k_lm_decide(DeviceProblem d, const double
     const double cost_t = s[SC_COST_T];
     const double pred = -(s[SC_GDOT] + s[SC_GDOT_C]) - 0.5 * (s[SC_DHD] + s[SC_DHD_C]);
     double rho = (pred > 0.0 && isfinite(cost_t)) ? (cost - cost_t) / pred : -1.0;
-    if (h.guard_cheirality && s[SC_NBEHIND_T] > h.nbehind) rho = -1.0;
+    if (h.guard_cheirality && s[SC_NBEHIND_T] > h.nbehind) { rho = -1.0; h.guard_rejections++; }
+    h.shortened_steps += (int)fmin(s[SC_NSHORT], 1e9);
+    // a factorisation that met a non-positive pivot (or a landmark / camera block that was not positive definite)
+    // solved a perturbed system: its step is not trusted, and more damping is the cure
+    if (s[SC_BADV] > 0.0) { rho = -1.0; h.bad_pivots += (int)fmin(s[SC_BADV], 1e9); }
     const double step_norm = sqrt(s[SC_DNORM2] + s[SC_DNORM2_C]);
     const double x_norm = sqrt(s[SC_XNORM2] + s[SC_XNORM2_C]);
     const bool accept = rho > h.accept_ratio;
@@ -2020,6 +2055,7 @@ __global__ __launch_bounds__(256) void k_lm_decide(DeviceProblem d, const double
     c->lam_hist[hi] = h.lam;
     c->pcg_hist[hi] = pcg_it;
     c->acc_hist[hi] = accept;
+    if (accept && it - 1 < LM_ACC_BITS) c->acc_bits[(it - 1) >> 5] |= 1u << ((it - 1) & 31);
     c->trial_hist[hi] = cost_t;
     c->rho_hist[hi] = rho;
     c->ginf_hist[hi] = h.ginf;

@@ -163,6 +163,9 @@ struct ba_handle {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
   double* scal_fold = nullptr;  // device [SC_COUNT + 1]: folded scalars + point-gradient inf-norm
+  double* agree_dev = nullptr;  // device [2]: status agreement between the ranks (lives as long as the communicator)
+  hipError_t launch_err = hipSuccess;  // first kernel launch the runtime refused since the last check
+  bool agree_failed = false;  // an agreement of the current call has already delivered an error: make no further one
   long n_global = 0;            // observations over all ranks
 };
 
@@ -194,6 +197,42 @@ enum { KT_LIN = 0, KT_SCHUR, KT_BACKSUB, KT_COST, KT_PCG, KT_OTHER };
     if (r_ != ncclSuccess) return fail(h, BA_ERR_DEVICE, "%s failed: %s", #expr, (h)->rccl->GetErrorString(r_)); \
   } while (0)
 
+// A launch that the runtime refuses (bad grid or LDS size, an earlier sticky error) leaves no trace in the stream:
+// remember the first such error; the entry points turn it into BA_ERR_DEVICE at their next synchronisation.
+inline void note_launch(ba_handle* h) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess && h->launch_err == hipSuccess) h->launch_err = e;
+}
+int check_launches(ba_handle* h, const char* where) {
+  if (h->launch_err == hipSuccess) return BA_OK;
+  const hipError_t e = h->launch_err;
+  h->launch_err = hipSuccess;
+  return fail(h, BA_ERR_DEVICE, "%s: a kernel launch failed: %s", where, hipGetErrorString(e));
+}
+
+// Multi-rank calls agree on a status BEFORE their next data collective: a rank that returned early (a bad shard,
+// a failed allocation) would otherwise leave the others blocked inside RCCL, which has no deadline.  Every rank
+// contributes its local status; all of them get the maximum and return it.
+int agree_status(ba_handle* h, int local_rc, const char* where) {
+  if (h->world <= 1 || !h->comm) return local_rc;
+  double v[2] = {(double)local_rc, 0.0};
+  if (hipMemcpyAsync(h->agree_dev, v, sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+      h->rccl->AllReduce(h->agree_dev, h->agree_dev + 1, 1, ncclDouble, ncclMax, h->comm, h->stream) != ncclSuccess ||
+      hipMemcpyAsync(v + 1, h->agree_dev + 1, sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+      hipStreamSynchronize(h->stream) != hipSuccess)
+    return local_rc ? local_rc : fail(h, BA_ERR_DEVICE, "%s: the ranks could not agree on a status", where);
+  const int global_rc = (int)v[1];
+  if (global_rc) h->agree_failed = true;  // every rank stops making agreements for this call at the same point
+  if (local_rc) return local_rc;  // this rank's own message stands
+  if (global_rc) return fail(h, global_rc, "%s: another rank reported status %d (all ranks return it)", where, global_rc);
+  return BA_OK;
+}
+
+struct DevTmp {  // a device allocation that lives for one scope
+  void* p = nullptr;
+  ~DevTmp() { if (p) (void)hipFree(p); }
+};
+
 hipEvent_t next_event(ba_handle* h) {
   if (h->ev_used == h->ev_pool.size()) {
     hipEvent_t e;
@@ -208,8 +247,8 @@ hipEvent_t next_event(ba_handle* h) {
 void collect_spans(ba_handle* h, const LmCtrl& c) {
   for (auto& s : h->spans) {
     bool ran = s.iter < c.it;
-    if (ran && s.cls == KT_LIN && s.iter > 0)
-      ran = s.iter - 1 < LM_HISTORY ? c.acc_hist[s.iter - 1] != 0 : false;
+    if (ran && s.cls == KT_LIN && s.iter > 0)  // the linearisation of iteration i + 1 ran iff iteration i accepted its step
+      ran = s.iter - 1 < LM_ACC_BITS ? (c.acc_bits[(s.iter - 1) >> 5] >> ((s.iter - 1) & 31)) & 1u : false;
     float ms = 0.f;
     if (ran && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
       h->ktime_ms[s.cls] += ms;
@@ -283,6 +322,7 @@ void launch_timed_lds(ba_handle* h, int cls, void (*kern)(KArgs...), int grid, i
   } else {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, h->stream, args...);
   }
+  note_launch(h);
 }
 template <class... KArgs, class... Args>
 void launch_timed(ba_handle* h, int cls, void (*kern)(KArgs...), int grid, int block, Args... args) {
@@ -332,11 +372,12 @@ void launch_backsub(ba_handle* h, double lam, const double* pts, double* pts_t, 
   const int pb = grid_for(d.C);  // trailing blocks: pose retraction + camera step statistics
   const int grid = grid_for(groups * G) + pb;
   const double md = h->opt.min_diag;
+  const int guard = 0;  // explicit mode (debug export): the plain step; solver mode takes the option from the control block
   switch (G) {
-    case 8: launch_timed(h, KT_BACKSUB, k_backsub<8>, grid, 256, d, lam, md, pts, pts_t, lpg, poses, poses_t, pb); break;
-    case 16: launch_timed(h, KT_BACKSUB, k_backsub<16>, grid, 256, d, lam, md, pts, pts_t, lpg, poses, poses_t, pb); break;
-    case 32: launch_timed(h, KT_BACKSUB, k_backsub<32>, grid, 256, d, lam, md, pts, pts_t, lpg, poses, poses_t, pb); break;
-    default: launch_timed(h, KT_BACKSUB, k_backsub<64>, grid, 256, d, lam, md, pts, pts_t, lpg, poses, poses_t, pb); break;
+    case 8: launch_timed(h, KT_BACKSUB, k_backsub<8>, grid, 256, d, lam, md, pts, pts_t, lpg, poses, poses_t, pb, guard); break;
+    case 16: launch_timed(h, KT_BACKSUB, k_backsub<16>, grid, 256, d, lam, md, pts, pts_t, lpg, poses, poses_t, pb, guard); break;
+    case 32: launch_timed(h, KT_BACKSUB, k_backsub<32>, grid, 256, d, lam, md, pts, pts_t, lpg, poses, poses_t, pb, guard); break;
+    default: launch_timed(h, KT_BACKSUB, k_backsub<64>, grid, 256, d, lam, md, pts, pts_t, lpg, poses, poses_t, pb, guard); break;
   }
 }
 
@@ -387,7 +428,7 @@ int clear_accumulators(ba_handle* h, bool with_u) {
 void enqueue_linearize(ba_handle* h, const double* poses, const double* pts) {
   launch_linearize(h, poses, pts);
   if (h->schur_cpb > 0) return;  // staged path: k_gather_S sums the U / gc slabs
-  k_reduce_U<<<grid_for(27L * h->C, 16), 256, 0, h->stream>>>(h->d, poses == nullptr);
+  k_reduce_U<<<grid_for(27L * h->C, 16), 256, 0, h->stream>>>(h->d, poses == nullptr); note_launch(h);
 }
 
 // build S / rhs for damping lam (lam < 0: solver mode), precondition, solve for dc by block-Jacobi PCG
@@ -475,9 +516,9 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
     // atomics): the camera step is bit-identical on all ranks and needs no broadcast
     return BA_OK;
   }
-  k_damp_mirror<<<grid_for(d.nu), 256, 0, h->stream>>>(d, lam, o.min_diag);
+  k_damp_mirror<<<grid_for(d.nu), 256, 0, h->stream>>>(d, lam, o.min_diag); note_launch(h);
   const int gv = grid_for(6L * d.Cf);
-  k_pcg_init<<<gv, 256, 0, h->stream>>>(d, mode);
+  k_pcg_init<<<gv, 256, 0, h->stream>>>(d, mode); note_launch(h);
   const int every = std::max(1, o.pcg_check_every);
   int launched = 0;
   while (launched < o.pcg_max_iter) {
@@ -485,7 +526,7 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
     for (int i = 0; i < nb; ++i) {
       k_pcg_spmv<<<gv, 256, 0, h->stream>>>(d);
       k_pcg_update<<<gv, 256, 0, h->stream>>>(d);
-      k_pcg_dir<<<gv, 256, 0, h->stream>>>(d, tol2, o.pcg_max_iter);
+      k_pcg_dir<<<gv, 256, 0, h->stream>>>(d, tol2, o.pcg_max_iter); note_launch(h);
     }
     launched += nb;
     if (h->world > 1)  // all ranks must take the same number of PCG batches: follow rank 0's scalars
@@ -583,6 +624,7 @@ int lm_solve(ba_handle* h, ba_report* rep) {
     const long work = std::max<long>(3L * h->L, n_clear);
     k_init_solve<<<(int)std::min<long>(1024, (work + 255) / 256), 256, 0, h->stream>>>(
         d, (const double*)h->poses_init, (const double*)h->pts_init, static_cast<const LmHead&>(c), n_clear);
+    note_launch(h);
   }
 
   const int check_every =
@@ -607,7 +649,7 @@ int lm_solve(ba_handle* h, ba_report* rep) {
       if (h->world > 1) {
         // fold on the device, combine the ranks with one sum all-reduce (the max of the point-gradient norm
         // travels in per-rank slots)
-        k_fold_scalars<<<1, 128, 0, h->stream>>>(d, h->scal_fold, h->rank, h->world);
+        k_fold_scalars<<<1, 128, 0, h->stream>>>(d, h->scal_fold, h->rank, h->world); note_launch(h);
         NCCL_TRY(h, h->rccl->AllReduce(h->scal_fold, h->scal_fold, (size_t)SC_COUNT + h->world, ncclDouble, ncclSum,
                                        h->comm, h->stream));
         launch_timed(h, KT_OTHER, k_lm_decide, 1, 256, d, (const double*)h->scal_fold, h->world, h->mirror_dev, enq + 1);
@@ -622,7 +664,8 @@ int lm_solve(ba_handle* h, ba_report* rep) {
       if (clk::now() > spin_until) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         if (__atomic_load_n(&h->mirror->seq, __ATOMIC_ACQUIRE) != enq)
-          return fail(h, BA_ERR_DEVICE, "the LM control block did not reach the host");
+          return check_launches(h, "solve") ? BA_ERR_DEVICE
+                                            : fail(h, BA_ERR_DEVICE, "the LM control block did not reach the host");
         break;
       }
     }
@@ -632,6 +675,7 @@ int lm_solve(ba_handle* h, ba_report* rep) {
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   rep->solve_ms = ms_since(t0);
   collect_spans(h, c);
+  if ((rc = check_launches(h, "solve"))) return rc;
   if (c.error == 1) return fail(h, BA_ERR_NUMERICAL, "cannot project points with zero Z coordinates (division by zero)");
   if (c.error == 2) return fail(h, BA_ERR_NUMERICAL, "non-finite cost at the initial guess");
   h->poses_cur = d.poses_buf[c.sel];
@@ -645,6 +689,9 @@ int lm_solve(ba_handle* h, ba_report* rep) {
   rep->linearizations = c.linearizations;
   rep->status = c.status;
   rep->pcg_iters = c.pcg_total;
+  rep->bad_pivots = c.bad_pivots;
+  rep->guard_rejections = c.guard_rejections;
+  rep->shortened_steps = c.shortened_steps;
   rep->rms_reproj = h->n_global > 0 ? std::sqrt(2.0 * c.cost / (double)h->n_global) : 0.0;
   rep->n_history = c.n_hist;
   for (int i = 0; i < c.n_hist; ++i) {
@@ -676,7 +723,7 @@ int ba_device_count(void) {
 
 void ba_default_options(ba_options* o) {
   if (!o) return;
-  o->max_iters = 200;
+  o->max_iters = 2000;  // the reference's cap: max_nfev=2000 (bundle_adjustment.py:210)
   o->ftol = 1e-8;
   o->xtol = 1e-12;
   o->gtol = 1e-10;
@@ -735,6 +782,7 @@ void ba_destroy(ba_handle* h) {
   (void)hipSetDevice(h->device);
   free_problem(h);
   if (h->comm && h->rccl) (void)h->rccl->CommDestroy(h->comm);
+  if (h->agree_dev) (void)hipFree(h->agree_dev);
   if (h->scal_host) (void)hipHostFree(h->scal_host);
   if (h->ctrl_host) (void)hipHostFree(h->ctrl_host);
   if (h->mirror) (void)hipHostFree(h->mirror);
@@ -776,6 +824,7 @@ int ba_comm_init(ba_handle* h, int32_t rank, int32_t world, const char* id128) {
   HIP_TRY(h, hipSetDevice(h->device));
   ncclUniqueId id;
   std::memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+  HIP_TRY(h, hipMalloc((void**)&h->agree_dev, 2 * sizeof(double)));
   NCCL_TRY(h, h->rccl->CommInitRank(&h->comm, world, id, rank));
   h->rank = rank;
   h->world = world;
@@ -796,14 +845,59 @@ int ba_schur_block_count(const ba_handle* h, int64_t* nu) {
   return BA_OK;
 }
 
-int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t* obs_cam, const int32_t* obs_pt,
-                   const double* obs_uv, const double* intr, const uint8_t* fixed_in) {
-  if (!h) return BA_ERR_INVALID;
+}  // extern "C"
+
+namespace {
+int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t* obs_cam, const int32_t* obs_pt,
+                     const double* obs_uv, const double* intr, const uint8_t* fixed_in);
+
+// everything that can be wrong with the arguments of ba_set_problem, checked before any state changes
+int validate_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t* obs_cam, const int32_t* obs_pt,
+                     const double* obs_uv, const double* intr, const uint8_t* fixed_in) {
   if (C <= 0 || L <= 0 || n <= 0 || !obs_cam || !obs_pt || !obs_uv || !intr)
-    return fail(h, BA_ERR_INVALID, "set_problem: empty problem or null pointer (C=%d L=%d n=%d)", C, L, n);
+    return fail(h, BA_ERR_INVALID, "set_problem: empty problem or null pointer (C=%d L=%d n=%d)%s", C, L, n,
+                h->world > 1 ? "; in a multi-GPU solve every rank needs at least one landmark and one observation" : "");
   for (int i = 0; i < 7; ++i)
     if (!std::isfinite(intr[i])) return fail(h, BA_ERR_INVALID, "intrinsics[%d] is not finite", i);
   if (!(intr[0] > 0) || !(intr[1] > 0)) return fail(h, BA_ERR_INVALID, "focal lengths must be positive");
+  for (int k = 0; k < n; ++k) {
+    if (obs_cam[k] < 0 || obs_cam[k] >= C) return fail(h, BA_ERR_INVALID, "obs_cam[%d]=%d out of range", k, obs_cam[k]);
+    if (obs_pt[k] < 0 || obs_pt[k] >= L) return fail(h, BA_ERR_INVALID, "obs_pt[%d]=%d out of range", k, obs_pt[k]);
+    if (!std::isfinite(obs_uv[2 * (size_t)k]) || !std::isfinite(obs_uv[2 * (size_t)k + 1]))
+      return fail(h, BA_ERR_INVALID, "observation %d is not finite", k);
+  }
+  if (fixed_in) {
+    int nfree = 0;
+    for (int c = 0; c < C; ++c) nfree += fixed_in[c] ? 0 : 1;
+    if (nfree == 0) return fail(h, BA_ERR_INVALID, "every pose is fixed: nothing to optimise");
+  } else if (C < 2) {
+    return fail(h, BA_ERR_INVALID, "every pose is fixed: nothing to optimise");
+  }
+  return BA_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t* obs_cam, const int32_t* obs_pt,
+                   const double* obs_uv, const double* intr, const uint8_t* fixed_in) {
+  if (!h) return BA_ERR_INVALID;
+  h->agree_failed = false;
+  // multi-GPU: no rank goes on to the pattern-union collectives unless every rank's arguments are good, and no
+  // rank keeps the problem unless every rank built it
+  int rc = agree_status(h, validate_problem(h, C, L, n, obs_cam, obs_pt, obs_uv, intr, fixed_in), "set_problem");
+  if (rc) return rc;
+  rc = set_problem_impl(h, C, L, n, obs_cam, obs_pt, obs_uv, intr, fixed_in);
+  if (!h->agree_failed) rc = agree_status(h, rc, "set_problem");
+  if (rc) free_problem(h);
+  return rc;
+}
+
+}  // extern "C"
+
+namespace {
+int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t* obs_cam, const int32_t* obs_pt,
+                     const double* obs_uv, const double* intr, const uint8_t* fixed_in) {
   const auto t0 = clk::now();
   HIP_TRY(h, hipSetDevice(h->device));
   free_problem(h);
@@ -822,13 +916,7 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
 
   // ---- tracks: observations grouped by landmark, camera-sorted inside a track
   std::vector<int> cnt(L + 1, 0);
-  for (int k = 0; k < n; ++k) {
-    if (obs_cam[k] < 0 || obs_cam[k] >= C) return fail(h, BA_ERR_INVALID, "obs_cam[%d]=%d out of range", k, obs_cam[k]);
-    if (obs_pt[k] < 0 || obs_pt[k] >= L) return fail(h, BA_ERR_INVALID, "obs_pt[%d]=%d out of range", k, obs_pt[k]);
-    if (!std::isfinite(obs_uv[2 * (size_t)k]) || !std::isfinite(obs_uv[2 * (size_t)k + 1]))
-      return fail(h, BA_ERR_INVALID, "observation %d is not finite", k);
-    cnt[obs_pt[k] + 1]++;
-  }
+  for (int k = 0; k < n; ++k) cnt[obs_pt[k] + 1]++;
   std::vector<int> uptr(L + 1, 0);
   for (int j = 0; j < L; ++j) uptr[j + 1] = uptr[j] + cnt[j + 1];
   std::vector<int> track(n);
@@ -909,8 +997,10 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
     // Every rank must use the SAME block pattern (the all-reduce sums S slot by slot): take the union of
     // the ranks' patterns.  Also sum the observation counts (for the RMS reprojection error).
     double cnt[2] = {(double)keys.size(), (double)n};
-    double* d_cnt = nullptr;
-    HIP_TRY(h, hipMalloc((void**)&d_cnt, 4 * sizeof(double)));
+    DevTmp t_cnt, t_mine, t_all;
+    int rc_a = hipMalloc(&t_cnt.p, 4 * sizeof(double)) == hipSuccess ? BA_OK : fail(h, BA_ERR_NOMEM, "set_problem: device allocation failed");
+    if ((rc_a = agree_status(h, rc_a, "set_problem"))) return rc_a;
+    double* d_cnt = static_cast<double*>(t_cnt.p);
     HIP_TRY(h, hipMemcpy(d_cnt, cnt, 2 * sizeof(double), hipMemcpyHostToDevice));
     NCCL_TRY(h, h->rccl->GroupStart());
     NCCL_TRY(h, h->rccl->AllReduce(d_cnt, d_cnt + 2, 1, ncclDouble, ncclMax, h->comm, h->stream));
@@ -918,20 +1008,20 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
     NCCL_TRY(h, h->rccl->GroupEnd());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(cnt, d_cnt + 2, 2 * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipFree(d_cnt);
     const size_t kmax = (size_t)cnt[0];
     h->n_global = (long)cnt[1];
     std::vector<int64_t> mine(kmax, -1), all((size_t)h->world * kmax);
     std::copy(keys.begin(), keys.end(), mine.begin());
-    int64_t *d_mine = nullptr, *d_all = nullptr;
-    HIP_TRY(h, hipMalloc((void**)&d_mine, kmax * sizeof(int64_t)));
-    HIP_TRY(h, hipMalloc((void**)&d_all, all.size() * sizeof(int64_t)));
+    rc_a = (hipMalloc(&t_mine.p, kmax * sizeof(int64_t)) == hipSuccess &&
+            hipMalloc(&t_all.p, all.size() * sizeof(int64_t)) == hipSuccess)
+               ? BA_OK : fail(h, BA_ERR_NOMEM, "set_problem: device allocation failed");
+    if ((rc_a = agree_status(h, rc_a, "set_problem"))) return rc_a;
+    int64_t* d_mine = static_cast<int64_t*>(t_mine.p);
+    int64_t* d_all = static_cast<int64_t*>(t_all.p);
     HIP_TRY(h, hipMemcpy(d_mine, mine.data(), kmax * sizeof(int64_t), hipMemcpyHostToDevice));
     NCCL_TRY(h, h->rccl->AllGather(d_mine, d_all, kmax, ncclInt64, h->comm, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(all.data(), d_all, all.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
-    (void)hipFree(d_mine);
-    (void)hipFree(d_all);
     keys.clear();
     for (int64_t k : all)
       if (k >= 0) keys.push_back(k);
@@ -1426,13 +1516,18 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
   h->setup_ms = ms_since(t0);
   return BA_OK;
 }
+}  // namespace
+
+extern "C" {
 
 int ba_upload_guess(ba_handle* h, const double* poses, const double* points) {
   if (!h) return BA_ERR_INVALID;
-  if (!h->has_problem) return fail(h, BA_ERR_STATE, "upload_guess before set_problem");
-  if (!poses || !points) return fail(h, BA_ERR_INVALID, "null poses/points");
+  if (!h->has_problem) return fail(h, BA_ERR_STATE, "upload_guess before set_problem");  // (no problem: no collective either)
+  if (!poses || !points) return agree_status(h, fail(h, BA_ERR_INVALID, "null poses/points"), "upload_guess");
   HIP_TRY(h, hipSetDevice(h->device));
-  int rc = stage_state(h, poses, points, h->poses_init, h->pts_init);
+  h->agree_failed = false;
+  // multi-GPU: the points are rank-local; a non-finite guess on one rank must stop every rank before the solve
+  int rc = agree_status(h, stage_state(h, poses, points, h->poses_init, h->pts_init), "upload_guess");
   if (rc) return rc;
   h->has_guess = true;
   h->has_estimate = false;
@@ -1441,7 +1536,9 @@ int ba_upload_guess(ba_handle* h, const double* poses, const double* points) {
 
 int ba_solve_resident(ba_handle* h, ba_report* report) {
   if (!h) return BA_ERR_INVALID;
-  if (!h->has_guess) return fail(h, BA_ERR_STATE, "solve before upload_guess");
+  h->agree_failed = false;
+  int rc = agree_status(h, h->has_guess ? BA_OK : fail(h, BA_ERR_STATE, "solve before upload_guess"), "solve");
+  if (rc) return rc;
   ba_report local;
   HIP_TRY(h, hipSetDevice(h->device));
   return lm_solve(h, report ? report : &local);
@@ -1466,6 +1563,8 @@ int ba_solve_batched(ba_handle* h, int32_t B, const int32_t* cam_off, const int3
                      const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv, const double* intr,
                      double* poses, double* points, double* cost0, double* cost, ba_report* report) {
   if (!h) return BA_ERR_INVALID;
+  if (h->world > 1)  // windows are independent: ranks take disjoint sets of windows, each with a handle of its own
+    return fail(h, BA_ERR_STATE, "solve_batched needs no communicator: use a handle without ba_comm_init per rank");
   if (B <= 0 || !cam_off || !lm_off || !obs_off || !obs_cam || !obs_pt || !obs_uv || !intr || !poses || !points)
     return fail(h, BA_ERR_INVALID, "solve_batched: empty batch or null pointer");
   if (cam_off[0] != 0 || lm_off[0] != 0 || obs_off[0] != 0)
@@ -1524,8 +1623,9 @@ int ba_evaluate(ba_handle* h, const double* poses, const double* points, double*
   launch_cost(h, h->d.poses_buf[1], h->d.pts_buf[1], SC_COST_T, SC_NBEHIND_T, d_res);
   if (residuals)
     HIP_TRY(h, hipMemcpyAsync(residuals, d_res, (size_t)2 * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if ((rc = fetch_scalars(h))) return rc;
+  rc = fetch_scalars(h);
   if (d_res) (void)hipFree(d_res);
+  if (rc || (rc = check_launches(h, "evaluate"))) return rc;
   if (cost) *cost = h->scal_host[SC_COST_T];
   if (n_behind) *n_behind = (int32_t)h->scal_host[SC_NBEHIND_T];
   if (h->scal_host[SC_ZEROZ] > 0.0)
@@ -1594,6 +1694,8 @@ int ba_triangulate(ba_handle* h, const double* poses, int32_t refine_iters, doub
   if (d_err) (void)hipFree(d_err);
   if (d_valid) (void)hipFree(d_valid);
   if (e != hipSuccess) return fail(h, BA_ERR_DEVICE, "triangulate: %s", hipGetErrorString(e));
+  note_launch(h);
+  { const int rc_l = check_launches(h, "triangulate"); if (rc_l) return rc_l; }
   const double nan = std::numeric_limits<double>::quiet_NaN();
   if (reproj_err) for (int j = 0; j < h->L; ++j) reproj_err[j] = nan;
   if (valid) std::memset(valid, 0, (size_t)h->L);
@@ -1614,16 +1716,16 @@ int ba_jacobian_blocks(ba_handle* h, const double* poses, const double* points, 
   int rc = stage_state(h, poses, points, h->d.poses_buf[1], h->d.pts_buf[1]);
   if (rc) return rc;
   h->has_estimate = false;
-  double *dJc = nullptr, *dJp = nullptr;
-  HIP_TRY(h, hipMalloc((void**)&dJc, (size_t)12 * h->n * sizeof(double)));
-  HIP_TRY(h, hipMalloc((void**)&dJp, (size_t)6 * h->n * sizeof(double)));
-  k_export_jac<<<std::min(grid_for(h->n), 4096), 256, 0, h->stream>>>(h->d, h->d.poses_buf[1], h->d.pts_buf[1], dJc, dJp);
+  DevTmp t_jc, t_jp;
+  HIP_TRY(h, hipMalloc(&t_jc.p, (size_t)12 * h->n * sizeof(double)));
+  HIP_TRY(h, hipMalloc(&t_jp.p, (size_t)6 * h->n * sizeof(double)));
+  double *dJc = static_cast<double*>(t_jc.p), *dJp = static_cast<double*>(t_jp.p);
+  k_export_jac<<<std::min(grid_for(h->n), 4096), 256, 0, h->stream>>>(h->d, h->d.poses_buf[1], h->d.pts_buf[1], dJc, dJp); note_launch(h);
   HIP_TRY(h, hipMemcpyAsync(Jc, dJc, (size_t)12 * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipMemcpyAsync(Jp, dJp, (size_t)6 * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  (void)hipFree(dJc);
-  (void)hipFree(dJp);
-  return BA_OK;
+  const hipError_t e_sync = hipStreamSynchronize(h->stream);
+  if (e_sync != hipSuccess) return fail(h, BA_ERR_DEVICE, "jacobian_blocks: %s", hipGetErrorString(e_sync));
+  return check_launches(h, "jacobian_blocks");
 }
 
 int ba_debug_linearization(ba_handle* h, const double* poses, const double* points, double lambda, double* U,
@@ -1648,7 +1750,7 @@ int ba_debug_linearization(ba_handle* h, const double* poses, const double* poin
   if ((rc = do_reduced_solve(h, lambda, &pcg_it))) return rc;
   HIP_TRY(h, hipMemcpyAsync(X1, X0, (size_t)3 * L * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   enqueue_trial(h, lambda, P0, X0, P1, X1);
-  if ((rc = fetch_scalars(h))) return rc;
+  if ((rc = fetch_scalars(h)) || (rc = check_launches(h, "debug_linearization"))) return rc;
   auto fetch = [&](std::vector<double>& dst, const double* src, size_t count) -> int {
     dst.resize(count);
     HIP_TRY(h, hipMemcpy(dst.data(), src, count * sizeof(double), hipMemcpyDeviceToHost));

@@ -233,11 +233,13 @@ def _euler_to_quat_batch(e: np.ndarray) -> np.ndarray:
                      (m[:, 1, 0] - m[:, 0, 1]) * s], axis=1)
 
 
-def ring_poses(C: int, radius: float = 6.0, height: float = 1.0) -> np.ndarray:
+def ring_poses(C: int, radius: float = 6.0, height: float = 1.0, spacing_of: int = 0) -> np.ndarray:
     """World poses of the ring trajectory: reference camera_pose.py:282-367 with time_step 0.1,
-    angular_velocity 2*pi/(C*0.1), look_at_center, offset = look-straight quaternion."""
+    angular_velocity 2*pi/(C*0.1), look_at_center, offset = look-straight quaternion.
+    ``spacing_of`` = N > 0 puts the C cameras on an ARC with the camera spacing of an N-camera ring
+    (down-scaled scenes with the geometry of a much larger ring, e.g. the 3.8 mm baselines of config 4)."""
     ts = 0.1
-    av = 2 * np.pi / (C * 0.1)
+    av = 2 * np.pi / ((spacing_of or C) * 0.1)
     offset = CameraPose.create_look_straight_pose().quaternion
     i = np.arange(C)
     angle = 0.0 + i * av * ts
@@ -276,14 +278,14 @@ def random_observation_index(C: int, L: int, d: int, seed: int) -> Tuple[np.ndar
 
 
 def ring_scene(C: int, L: int, d: int, sigma_px: float = 0.5, seed: int = 0, f: float = 500.0,
-               visibility: str = "ring") -> Scene:
+               visibility: str = "ring", spacing_of: int = 0) -> Scene:
     """SURVEY.md Appendix C ``ring_CxL``: cfg2 = (50, 20000, 10), cfg3 = (1000, 200000, 5),
     cfg4 = (10000, 2000000, 5).  Fully vectorised (no per-landmark Python loops).  ``visibility="random"``
     keeps the geometry but lets every landmark be seen by d random cameras (images then have unequal
     observation counts: a stress case for the solver, not a reference-compatible scene)."""
     rng = np.random.default_rng(seed)
     intr = np.array([f, f, 320.0, 240.0, 0.0, 0.0, 0.0])
-    poses_w = ring_poses(C)
+    poses_w = ring_poses(C, spacing_of=spacing_of)
     r = 1.5 * np.sqrt(rng.uniform(0, 1, L))
     th = rng.uniform(0, 2 * np.pi, L)
     z = rng.uniform(0, 2, L)

@@ -37,6 +37,8 @@ class BaReport(C.Structure):
         ("cost0", C.c_double), ("cost", C.c_double), ("grad_inf", C.c_double), ("lambda_", C.c_double),
         ("rms_reproj", C.c_double), ("iterations", C.c_int32), ("accepted", C.c_int32),
         ("linearizations", C.c_int32), ("status", C.c_int32), ("pcg_iters", C.c_int32), ("nobs", C.c_int32),
+        ("bad_pivots", C.c_int32), ("guard_rejections", C.c_int32), ("shortened_steps", C.c_int32),
+        ("reserved_", C.c_int32),
         ("solve_ms", C.c_double), ("setup_ms", C.c_double), ("n_history", C.c_int32),
         ("cost_history", C.c_double * BA_HISTORY), ("lambda_history", C.c_double * BA_HISTORY),
         ("pcg_history", C.c_int32 * BA_HISTORY), ("accepted_history", C.c_int32 * BA_HISTORY),
@@ -48,6 +50,8 @@ class BaReport(C.Structure):
                     rms_reproj=self.rms_reproj, iterations=self.iterations, accepted=self.accepted,
                     linearizations=self.linearizations, status=self.status,
                     status_name=STATUS_NAMES.get(self.status, "?"), pcg_iters=self.pcg_iters, nobs=self.nobs,
+                    bad_pivots=self.bad_pivots, guard_rejections=self.guard_rejections,
+                    shortened_steps=self.shortened_steps,
                     solve_ms=self.solve_ms, setup_ms=self.setup_ms, cost_history=list(self.cost_history[:n]),
                     lambda_history=list(self.lambda_history[:n]), pcg_history=list(self.pcg_history[:n]),
                     accepted_history=list(self.accepted_history[:n]))
