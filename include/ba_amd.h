@@ -52,8 +52,10 @@ typedef enum {
   BA_SOLVER_AUTO = 0,
   BA_SOLVER_PCG = 1,
   BA_SOLVER_DENSE_CHOLESKY = 2,
-  BA_SOLVER_BANDED_CHOLESKY = 3 /* block-banded (+ arrow) Cholesky: cameras that only share landmarks with their
-                                   neighbours along a trajectory, possibly closed into a loop */
+  BA_SOLVER_BANDED_CHOLESKY = 3, /* block-banded (+ arrow) Cholesky: cameras that only share landmarks with their
+                                    neighbours along a trajectory, possibly closed into a loop */
+  BA_SOLVER_CYCLIC_REDUCTION = 4 /* the same systems by block cyclic reduction (every other group of cameras eliminated at
+                                    once, log2 depth): what AUTO takes for a long trajectory */
 } ba_linear_solver;
 
 /* Robust loss, applied to every scalar residual with the semantics of the `loss=` / `f_scale=`
@@ -253,9 +255,10 @@ int ba_debug_linearization(ba_handle* h, const double* poses, const double* poin
 
 /* Device time per kernel class, measured with HIP events on the solver's own stream during the
  * solves since the last ba_set_problem (needs opt.profile_kernels = 1).  Classes:
- * 0 k_linearize, 1 k_schur, 2 k_backsub, 3 k_cost, 4 PCG (all its launches), 5 k_schur_init +
- * k_damp_mirror + k_pose_update + memsets.  No reference counterpart (bench.py's roofline figures). */
-#define BA_KERNEL_CLASSES 6
+ * 0 k_linearize*, 1 k_schur*, 2 k_backsub, 3 k_cost, 4 the reduced camera solve (one-workgroup PCG, or every launch of
+ * the Cholesky solvers), 5 other (k_block_precond, k_triangulate), 6 k_gather_S / k_reduce_S, 7 k_lm_decide.
+ * No reference counterpart (bench.py's roofline figures). */
+#define BA_KERNEL_CLASSES 8
 int ba_get_kernel_times(ba_handle* h, double* total_ms, int32_t* launches);
 /* Switch the per-launch start/stop events (ba_options.profile_kernels) on or off for later solves.
  * No counterpart in the reference; used by bench.py, which times the solves without events and then
@@ -285,8 +288,18 @@ int ba_comm_init(ba_handle* h, int32_t rank, int32_t world, const char* id128);
 
 /* Which solver ba_set_problem chose for the reduced camera system: 0 multi-kernel PCG, 1 one-workgroup PCG,
  * 2 whole-GPU dense Cholesky, 3 banded + arrow Cholesky, 4 dense Cholesky per connected component (batched
- * windows).  No reference counterpart. */
+ * windows), 5 block cyclic reduction.  No reference counterpart. */
 int ba_reduced_solver(const ba_handle* h, int32_t* kind);
+
+/* Sizes behind the per-kernel byte counts of bench.py (no reference counterpart): info[BA_INFO_COUNT] =
+ * 0 stored upper 6x6 blocks of S, 1 contribution rows (42 doubles each) that the staged Schur kernel writes and the
+ * gather reads per launch (0 on the atomics path), 2 Schur chunks, 3 copies of the U / gc slabs, 4 reduced solver (as
+ * ba_reduced_solver), 5 / 6 half-bandwidth and arrow size of the banded solver (level 2 when segmented; cyclic reduction:
+ * cameras per super-block and levels), 7 segments of the two-level banded solver (0: one level; cyclic reduction:
+ * super-blocks), 8 free cameras, 9 observed landmarks, 10 1 if k_linearize_flat is used,
+ * 11 connected components of the camera graph. */
+#define BA_INFO_COUNT 12
+int ba_problem_info(const ba_handle* h, int64_t* info);
 
 /* Number of stored 6x6 blocks of the reduced camera system (upper triangle incl. diagonal). */
 int ba_schur_block_count(const ba_handle* h, int64_t* n_upper_blocks);

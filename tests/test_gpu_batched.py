@@ -155,10 +155,11 @@ def test_banded_cholesky_step_matches_oracle(make, segments, monkeypatch):
 
 
 def test_banded_cholesky_is_chosen_and_converges_like_dense():
-    """AUTO takes the banded solver for a long trajectory; the solve follows the dense Cholesky's path."""
+    """The banded solver on a long trajectory (AUTO now takes cyclic reduction there, tests/test_gpu_cyclic_reduction.py):
+    the solve follows the dense Cholesky's path."""
     sc = scenes.ring_scene(300, 6000, 5)
     reps = {}
-    for name, opt in (("auto", {}), ("dense", dict(linear_solver=2))):
+    for name, opt in (("auto", dict(linear_solver=3)), ("dense", dict(linear_solver=2))):
         with _native.Solver(**opt) as s:
             s.set_problem(300, 6000, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
             reps[name] = (s.reduced_solver(), s.solve(sc["poses_guess"], sc["points_guess"])[2])

@@ -68,7 +68,7 @@ def test_config4_full_size_properties(config4, tolerances):
     opts = dict(ftol=1e-6, xtol=1e-6, gtol=1e-6) if tolerances == "reference" else {}
     with _native.Solver(**opts) as s:
         s.set_problem(C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
-        assert s.reduced_solver() == "banded_cholesky"
+        assert s.reduced_solver() == "cyclic_reduction"
         P, X, rep = s.solve(sc["poses_guess"], sc["points_guess"])
         _, cost_eval, nb = s.evaluate(P, X, want_residuals=False)
         _, _, rep2 = s.solve(P, X) if tolerances == "reference" else (None, None, None)

@@ -1,0 +1,102 @@
+"""Block cyclic reduction of a trajectory's reduced camera system (csrc/ba_bcr.h) through the C ABI: one LM step against a
+dense numpy solve of the system the library itself exports (1e-9 relative, the bar of the banded Cholesky it replaces),
+over closed loops and open trajectories, bandwidths 2 ... 6, camera counts that leave padded super-blocks and every
+small block count (3 ... 9: the recursion's odd / even / merged levels), and whole solves against the other solvers."""
+
+import numpy as np
+import pytest
+
+import scenes
+from oracle import lm_schur_numpy as lm
+from src import _native
+
+pytestmark = pytest.mark.gpu
+
+
+def _open_trajectory(C, L, d):
+    sc = scenes.ring_scene(C, L, d)
+    keep = sc["obs_cam"] >= (sc["obs_pt"] % C)
+    return dict(sc, obs_cam=sc["obs_cam"][keep], obs_pt=sc["obs_pt"][keep], obs_uv=sc["obs_uv"][keep])
+
+
+def _step(sc, lam, **opt):
+    C, L = len(sc["poses_gt"]), len(sc["points_gt"])
+    with _native.Solver(linear_solver=4, **opt) as s:
+        s.set_problem(C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+        assert s.reduced_solver() == "cyclic_reduction"
+        info = s.problem_info()
+        out = s.debug_linearization(sc["poses_guess"], sc["points_guess"], lam, want_S=True)
+    dc = np.linalg.solve(out["S"], -out["rhs"]).reshape(C, 6)
+    dc[0] = 0.0
+    np.testing.assert_allclose(out["dc"], dc, rtol=0, atol=1e-9 * np.abs(dc).max())
+    return out, info
+
+
+@pytest.mark.parametrize("make", [lambda: scenes.ring_scene(60, 1200, 5), lambda: _open_trajectory(60, 1200, 5)],
+                         ids=["closed_loop", "open_trajectory"])
+def test_cyclic_reduction_step_matches_oracle(make):
+    """Against the oracle's own reduced system and back-substitution (not only the library's exported S)."""
+    sc = make()
+    C, L = len(sc["poses_gt"]), len(sc["points_gt"])
+    lam = 1e-3
+    out, info = _step(sc, lam)
+    assert info["band_bw"] in (4, 5)  # cameras per super-block: the half-bandwidth (4), or one more where 59 = 14 x 4 + 3
+    r, Jc, Jp = lm.linearize(sc["poses_guess"], sc["points_guess"], sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+    free = np.ones(C, bool)
+    free[0] = False
+    Jc = Jc * free[sc["obs_cam"]][:, None, None]
+    U, V, W, gc, gp, _ = lm.normal_blocks(r, Jc, Jp, sc["obs_cam"], sc["obs_pt"], C, L)
+    S, rhs, Vi = lm.schur_system(U, V, W, gc, gp, sc["obs_cam"], sc["obs_pt"], lam, free)
+    dc = np.linalg.solve(S, -rhs).reshape(C, 6) * free[:, None]
+    dp = lm.back_substitute(dc, Vi, W, gp, sc["obs_cam"], sc["obs_pt"], L)
+    np.testing.assert_allclose(out["dc"], dc, rtol=0, atol=1e-9 * np.abs(dc).max())
+    np.testing.assert_allclose(out["dp"], dp, rtol=0, atol=1e-9 * np.abs(dp).max())
+
+
+@pytest.mark.parametrize("C,d", [(13, 5), (17, 5), (21, 5), (25, 5), (29, 5), (33, 5), (37, 5), (41, 5),   # 3 ... 10 blocks of 4
+                                 (120, 3), (121, 4), (123, 7), (200, 6), (257, 5)])
+def test_cyclic_reduction_block_counts_and_bandwidths(C, d):
+    """C - 1 free cameras in super-blocks of d - 1: every small block count (levels with an odd count, an even count, the
+    merged two-block level, the single last block), padded blocks (C - 1 not a multiple), bandwidths 2 ... 6."""
+    L = 20 * C
+    out, info = _step(scenes.ring_scene(C, L, d), 1e-2)
+    assert info["band_segments"] == (C - 1) // (d - 1)
+
+
+def test_cyclic_reduction_is_chosen_and_follows_the_other_direct_solvers():
+    """AUTO takes cyclic reduction for a long trajectory; the solve follows the dense and the banded Cholesky's path
+    (same iterations, cost to 1e-9)."""
+    sc = scenes.ring_scene(300, 6000, 5)
+    reps = {}
+    for name, opt in (("auto", {}), ("dense", dict(linear_solver=2)), ("banded", dict(linear_solver=3))):
+        with _native.Solver(**opt) as s:
+            s.set_problem(300, 6000, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+            reps[name] = (s.reduced_solver(), s.solve(sc["poses_guess"], sc["points_guess"])[2])
+    assert [reps[k][0] for k in ("auto", "dense", "banded")] == ["cyclic_reduction", "dense_cholesky", "banded_cholesky"]
+    a = reps["auto"][1]
+    for other in ("dense", "banded"):
+        b = reps[other][1]
+        assert a["iterations"] == b["iterations"] and a["status"] == b["status"] and a["bad_pivots"] == 0
+        assert abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"]
+
+
+def test_cyclic_reduction_is_bitwise_reproducible():
+    """No atomics anywhere in the solver: two solves of one problem give the same bits in the camera step (what lets
+    every rank of a multi-GPU solve factor the all-reduced system by itself, without a broadcast)."""
+    sc = scenes.ring_scene(120, 2400, 5)
+    outs = []
+    for _ in range(2):
+        with _native.Solver(linear_solver=4) as s:
+            s.set_problem(120, 2400, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+            outs.append(s.debug_linearization(sc["poses_guess"], sc["points_guess"], 1e-3, want_S=True))
+    if np.array_equal(outs[0]["S"], outs[1]["S"]) and np.array_equal(outs[0]["rhs"], outs[1]["rhs"]):
+        np.testing.assert_array_equal(outs[0]["dc"], outs[1]["dc"])
+    else:  # U / gc come through fp64 atomics in k_linearize: only then may the system itself differ in the last bits
+        np.testing.assert_allclose(outs[0]["dc"], outs[1]["dc"], rtol=0, atol=1e-9 * np.abs(outs[0]["dc"]).max())
+
+
+def test_cyclic_reduction_rejects_unstructured_problems():
+    sc = scenes.ring_scene(200, 4000, 5, visibility="random")
+    with _native.Solver(linear_solver=4) as s:
+        with pytest.raises(Exception):
+            s.set_problem(200, 4000, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])

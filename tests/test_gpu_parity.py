@@ -294,8 +294,8 @@ def test_config2_full_size_properties(golden):
 
 
 def test_config3_full_size_properties(golden):
-    """BASELINE configs[2] (1000 cameras x 200 000 landmarks x 1 000 000 observations; AUTO takes the two-level banded
-    Cholesky), run to termination with the defaults: one-sided against the cost the reference's least_squares call
+    """BASELINE configs[2] (1000 cameras x 200 000 landmarks x 1 000 000 observations; AUTO takes block cyclic
+    reduction), run to termination with the defaults: one-sided against the cost the reference's least_squares call
     reached on this scene (17 evaluations, 400 s on one core; it stops on ftol = 1e-6 about 1e-4 above the minimum)
     and TWO-sided 1e-6 against the polished minimum (tests/golden/ring_1000x200000.npz); cost == ba_evaluate's; every
     accepted step lowered the cost; a second solve from the estimate changes the cost by less than 1e-7."""
@@ -305,7 +305,7 @@ def test_config3_full_size_properties(golden):
     C, L = len(sc["poses_guess"]), len(sc["points_guess"])
     with _native.Solver() as s:
         s.set_problem(C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
-        assert s.reduced_solver() == "banded_cholesky"
+        assert s.reduced_solver() == "cyclic_reduction"
         P, X, rep = s.solve(sc["poses_guess"], sc["points_guess"])
         _, cost_eval, nb = s.evaluate(P, X, want_residuals=False)
         _, _, rep2 = s.solve(P, X)

@@ -84,12 +84,12 @@ def test_sharded_unstructured_scene_takes_the_union_of_block_patterns(tmp_path):
 
 
 def test_sharded_direct_solver(tmp_path):
-    """Two ranks with the banded Cholesky (300 cameras in a ring): the factorisation runs replicated on the
+    """Two ranks with a direct solver (300 cameras in a ring: cyclic reduction): the factorisation runs replicated on the
     all-reduced system."""
     sc = scenes.ring_scene(300, 3000, 6)
     P0, X0, rep0 = single_gpu(sc, ftol=1e-12)
     parts = run_ranks(2, "ring_long", tmp_path, ftol=1e-12)
-    assert str(parts[0]["solver"]) == "banded_cholesky"
+    assert str(parts[0]["solver"]) == "cyclic_reduction"
     check_against_single(parts, sc, P0, X0, rep0, atol=1e-6)
 
 

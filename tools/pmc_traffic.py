@@ -11,7 +11,8 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 CLASS = {"k_linearize": "k_linearize", "k_schur": "k_schur", "k_backsub": "k_backsub", "k_cost": "k_cost",
-         "k_solve_small": "pcg", "k_solve_components": "pcg", "k_gather_S": "k_gather_S"}
+         "k_solve_small": "pcg", "k_solve_components": "pcg", "k_gather_S": "k_gather_S",
+         "k_bseg_factor": "k_bseg_factor", "k_banded_factor": "k_banded_factor", "k_bseg_assemble": "k_bseg_assemble"}
 
 
 def per_kernel(d, counter):

@@ -1,0 +1,393 @@
+// Block cyclic reduction of the reduced camera system of a trajectory (gfx950, fp64).
+//
+// Cameras along a trajectory share landmarks only with their neighbours: with the free cameras grouped, in order,
+// into N super-blocks of at least `bwr` cameras each (bwr = the cyclic half-bandwidth of S in blocks), S is block
+// TRIDIAGONAL in super-blocks -- cyclic when the trajectory closes into a loop:
+//     D_i   (m x m, m = 6 x cameras per super-block, SPD)      the diagonal block of super-block i
+//     E_i   (m x m)                                              the block (i, i + 1 mod N)
+// ba_banded.h factors such a system column by column: a chain of C (one level) or C / P + P bw (two levels) dependent
+// 6-wide column steps of ~4.6 us each -- 0.85 ms per solve at 1000 cameras, 2.7 ms at 10 000, most of an LM iteration
+// and, with several GPUs, work that every rank repeats.  Cyclic reduction eliminates every other super-block at once:
+//     level l:  for every odd i (one workgroup each, k_bcr_factor):  D_i = L L^T,
+//                   Fa = E_{i-1} L^-T,  Fb = E_i^T L^-T,  y = L^-1 r_i,  L^-T itself
+//               for every even e (one workgroup each, k_bcr_update), the system of level l + 1 (half the blocks):
+//                   D'_{e/2} = D_e - Fb_{e-1} Fb_{e-1}^T - Fa_{e+1} Fa_{e+1}^T
+//                   E'_{e/2} = -Fa_{e+1} Fb_{e+1}^T            (= block (e, e + 2))
+//                   r'_{e/2} = r_e - Fb_{e-1} y_{e-1} - Fa_{e+1} y_{e+1}
+// until one block is left; then back up (k_bcr_backsolve): x_i = L^-T (y - Fa^T x_{i-1} - Fb^T x_{i+1}).
+// The chain is 2 ceil(log2 N) + 1 short kernels deep instead of hundreds of column steps, every level is as wide as
+// the chip, and all sums run in a fixed order (no atomics): the step is bitwise reproducible, which the multi-GPU
+// solve relies on.  The elimination is a block Cholesky in nested-dissection order: Schur complements of an SPD
+// matrix, as stable as the banded factorisation it replaces.
+//
+// Block layout: every m x m block row-major with row stride m; super-blocks with fewer than m / 6 cameras are padded
+// with identity rows (zero coupling, zero right-hand side).
+#pragma once
+#include "ba_banded.h"
+
+constexpr int BCR_THREADS = 256;
+constexpr int BCR_MAX_M = 48;      // 8 cameras per super-block
+constexpr int BCR_MAX_LEVELS = 24;
+
+struct BcrLevel {
+  int n;        // blocks at this level
+  int n_elim;   // blocks eliminated here: the odd ones (n / 2), or the single block of the last level
+  long D, E, r;            // offsets (doubles) of D [n][m*m], E [n][m*m], r [n][m]
+  long LiT, Fa, Fb, y;     // offsets of the factors of the eliminated blocks [n_elim][...]
+};
+
+struct BcrPlan {
+  int m, n_levels, N;
+  long X;                  // offset of x [N][m], indexed by the level-0 block
+  BcrLevel lv[BCR_MAX_LEVELS];
+};
+
+// ------------------------------------------------------------------------------------------------
+// k_bcr_assemble: the damped S (upper 6x6 blocks) and -rhs into the level-0 arrays, which must be zero.
+//   kind[s] 0: diagonal block of a camera (lower triangle mirrored), 1: block inside a D (written twice, mirrored),
+//           2: block of an E, as stored, 3: block of an E, transposed (the loop closure: block (N - 1, 0)).
+//   dst[s]  offset of the target of entry (0, 0) (for kind 1: of the upper copy; dst2[s] the mirrored copy)
+//   rdst[f] offset of the right-hand-side entries of free camera f;  pad[q]: offsets of padded diagonal entries (= 1).
+__global__ __launch_bounds__(256) void k_bcr_assemble(DeviceProblem d, double* __restrict__ B, int m,
+                                                      const long* __restrict__ dst, const long* __restrict__ dst2,
+                                                      const unsigned char* __restrict__ kind, const long* __restrict__ rdst,
+                                                      const long* __restrict__ pad, int n_pad, double lam, double min_diag,
+                                                      int solver_mode) {
+  if (solver_mode) {
+    if (d.ctrl->done) return;
+    lam = d.ctrl->lam;
+  }
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nS = (long)d.nu * 36;
+  if (t < nS) {
+    const int s = (int)(t / 36), e = (int)(t - 36L * s), r = e / 6, c = e - 6 * r;
+    double v = d.S[t];
+    const int k = kind[s];
+    double* blk = B + dst[s];
+    if (k == 0) {
+      if (c > r) return;
+      if (r == c) v += lam * fmax(u_diag(d, d.urow[s], r), min_diag);
+      blk[r * m + c] = v;
+      blk[c * m + r] = v;
+    } else if (k == 1) {
+      blk[r * m + c] = v;
+      B[dst2[s] + c * m + r] = v;
+    } else if (k == 2) {
+      blk[r * m + c] = v;
+    } else {
+      blk[c * m + r] = v;
+    }
+  } else if (t < nS + 6L * d.Cf) {
+    const long p = t - nS;
+    const int f = (int)(p / 6), e = (int)(p - 6L * f);
+    B[rdst[f] + e] = -d.rhs[p];
+  } else if (t < nS + 6L * d.Cf + n_pad) {
+    B[pad[t - nS - 6L * d.Cf]] = 1.0;
+  }
+}
+
+// L^-1 (lower, row-major 6x6) of the Cholesky factor of the SPD block at A (row stride `ld`, lower part used).
+__device__ __forceinline__ bool chol6_inverse_ld(const double* A, int ld, double Li[36]) {
+  double a[36];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) a[6 * i + j] = A[i * ld + j];
+  return chol6_inverse(a, Li);
+}
+
+constexpr int BCR_EPT = (BCR_MAX_M * BCR_MAX_M + BCR_THREADS - 1) / BCR_THREADS;  // entries of a block per thread
+
+// ------------------------------------------------------------------------------------------------
+// k_bcr_factor: one workgroup per eliminated block i of a level.  The tall matrix
+//     T = [ D_i ; E_{i-1} ; E_i^T ; I ; r_i^T ]        ((4 m + 1) x m, in LDS)
+// goes through a right-looking block Cholesky of its top m x m part, 6 columns at a time (every thread factors the
+// 6x6 diagonal block itself, as k_banded_factor does; a thread then scales one row of the panel; in the trailing
+// update a thread takes one row and one 6-wide column block: 6 panel entries and a 6x6 block of L out of LDS for 36
+// multiply-adds): what is left below D_i is Fa = E_{i-1} L^-T, Fb = E_i^T L^-T, L^-T and y^T = (L^-1 r_i)^T.
+// All global loads are issued before the first use (one round trip, not one per loop iteration).
+//   n == 2: the two couplings of blocks 0 and 1 (E_0 and, around the loop, E_1) are one block: Ea = E_0 + E_1^T, Eb = 0
+//   n == 1: the last block, no neighbours
+__global__ __launch_bounds__(BCR_THREADS) void k_bcr_factor(double* __restrict__ B, BcrPlan plan, int level, const LmCtrl* ctrl,
+                                                            double* __restrict__ badv) {
+  extern __shared__ double lds[];
+  if (ctrl && ctrl->done) return;
+  const BcrLevel lv = plan.lv[level];
+  const int m = plan.m, ld = m + 1, mm = m * m, nb = m / 6;
+  const int tid = threadIdx.x;
+  const int q = blockIdx.x;                    // q-th eliminated block
+  const int i = lv.n == 1 ? 0 : 2 * q + 1;     // its index at this level
+  const int R = 4 * m + 1;
+  double* T = lds;                             // [R][ld]
+  const double* __restrict__ Di = B + lv.D + (long)i * mm;
+  const bool has_nb = lv.n > 1;
+  const int ia = has_nb ? i - 1 : 0;
+  const double* __restrict__ Ea = B + lv.E + (long)ia * mm;   // block (i - 1, i)
+  const double* __restrict__ Eb = B + lv.E + (long)i * mm;    // block (i, i + 1)
+  const bool merged = lv.n == 2;
+  {
+    double vd[BCR_EPT], va[BCR_EPT], vb[BCR_EPT];
+#pragma unroll
+    for (int u = 0; u < BCR_EPT; ++u) {
+      const int e = tid + u * BCR_THREADS;
+      vd[u] = va[u] = vb[u] = 0.0;
+      if (e < mm) {
+        vd[u] = Di[e];
+        if (has_nb) { va[u] = Ea[e]; vb[u] = Eb[e]; }
+      }
+    }
+    const double rv = tid < m ? B[lv.r + (long)i * m + tid] : 0.0;
+#pragma unroll
+    for (int u = 0; u < BCR_EPT; ++u) {
+      const int e = tid + u * BCR_THREADS;
+      if (e < mm) {
+        const int r = e / m, c = e - r * m;
+        T[r * ld + c] = vd[u];
+        T[(3 * m + r) * ld + c] = r == c ? 1.0 : 0.0;
+        if (!merged) {
+          T[(m + r) * ld + c] = va[u];          // row r of block i - 1, column c of block i
+          T[(2 * m + c) * ld + r] = vb[u];      // E_i^T: E_i[r][c] is row c of block i + 1, column r of block i
+        } else {
+          T[(2 * m + r) * ld + c] = 0.0;
+        }
+      }
+    }
+    if (merged) {  // Ea = E_0 + E_1^T: two passes so that each entry has one writer at a time
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < BCR_EPT; ++u) {
+        const int e = tid + u * BCR_THREADS;
+        if (e < mm) { const int r = e / m, c = e - r * m; T[(m + r) * ld + c] = va[u]; }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < BCR_EPT; ++u) {
+        const int e = tid + u * BCR_THREADS;
+        if (e < mm) { const int r = e / m, c = e - r * m; T[(m + c) * ld + r] += vb[u]; }
+      }
+    }
+    if (tid < m) T[4 * m * ld + tid] = rv;
+  }
+  __syncthreads();
+  bool bad = false;
+  for (int j = 0; j < nb; ++j) {
+    const int c0 = 6 * j;
+    double Li[36];
+    if (!chol6_inverse_ld(T + c0 * ld + c0, ld, Li)) bad = true;  // (the panel below never writes the diagonal block)
+    // panel: row <- row * L_jj^-T for the rows below the diagonal block (D rows > block j, all coupling rows, the
+    // identity rows that can be non-zero here, the right-hand side)
+    for (int rho = tid; rho < R; rho += BCR_THREADS) {
+      const bool live = rho < m ? rho >= c0 + 6 : (rho >= 3 * m && rho < 4 * m ? rho - 3 * m < c0 + 6 : true);
+      if (!live) continue;
+      double* row = T + rho * ld + c0;
+      double x[6], o[6];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) x[t] = row[t];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t <= c; ++t) s += x[t] * Li[6 * c + t];
+        o[c] = s;
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) row[c] = o[c];
+    }
+    __syncthreads();
+    // trailing update: T[rho][c] -= sum_t T[rho][c0 + t] * L[c][c0 + t] for the columns c right of the panel;
+    // item = (row rho, column block kb)
+    const int nbc = nb - 1 - j;
+    for (int w = tid; w < R * nbc; w += BCR_THREADS) {
+      const int rho = w / nbc, kb = j + 1 + (w - rho * nbc), cb = 6 * kb;
+      if (rho < m) { if (rho < cb) continue; }                                  // D: blocks on or below the diagonal
+      else if (rho >= 3 * m && rho < 4 * m && rho - 3 * m >= c0 + 6) continue;  // identity rows still zero here
+      const double* a = T + rho * ld + c0;
+      double x[6];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) x[t] = a[t];
+      double* out = T + rho * ld + cb;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const double* b = T + (cb + c) * ld + c0;
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) s += x[t] * b[t];
+        out[c] -= s;
+      }
+    }
+    __syncthreads();
+  }
+  double* __restrict__ Fa = B + lv.Fa + (long)q * mm;
+  double* __restrict__ Fb = B + lv.Fb + (long)q * mm;
+  double* __restrict__ LiT = B + lv.LiT + (long)q * mm;
+  for (int e = tid; e < mm; e += BCR_THREADS) {
+    const int r = e / m, c = e - r * m;
+    Fa[e] = T[(m + r) * ld + c];
+    Fb[e] = T[(2 * m + r) * ld + c];
+    LiT[e] = c >= r ? T[(3 * m + r) * ld + c] : 0.0;
+  }
+  if (tid < m) B[lv.y + (long)q * m + tid] = T[4 * m * ld + tid];
+  if (bad && tid == 0) atomic_add_f64(badv, 1.0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_bcr_update: one workgroup per even block e of level l = block e / 2 of level l + 1 (formulas in the header).
+// A thread owns a 2 x 2 tile of the block (10 LDS reads per 12 multiply-adds); D' is symmetric, tiles above its
+// diagonal only compute the E' part.
+__global__ __launch_bounds__(BCR_THREADS) void k_bcr_update(double* __restrict__ B, BcrPlan plan, int level, const LmCtrl* ctrl) {
+  extern __shared__ double lds[];
+  if (ctrl && ctrl->done) return;
+  const BcrLevel lv = plan.lv[level], nx = plan.lv[level + 1];
+  const int m = plan.m, ld = m + 1, mm = m * m;
+  const int tid = threadIdx.x;
+  const int k = blockIdx.x, e = 2 * k, n = lv.n;
+  // odd neighbours (indices into the factor arrays), -1: none
+  int ql = -1, qr = -1;
+  if (n == 2) { qr = 0; }                                  // merged coupling lives in Fa of block 1
+  else {
+    if (e >= 1) ql = (e - 1) >> 1; else if ((n & 1) == 0) ql = (n - 1) >> 1;   // block 0's left neighbour is n - 1
+    if (e + 1 < n) qr = (e + 1) >> 1;
+  }
+  double* FbL = lds;                 // Fb of the left odd block  [m][ld]  (rows: block e)
+  double* FaR = FbL + m * ld;        // Fa of the right odd block [m][ld]  (rows: block e)
+  double* FbR = FaR + m * ld;        // Fb of the right odd block [m][ld]  (rows: block e + 2)
+  double* yL = FbR + m * ld;         // [m]
+  double* yR = yL + m;               // [m]
+  double* Dn_s = yR + m;             // [m][ld] D' staged for the mirrored write-out
+  const double* __restrict__ De = B + lv.D + (long)e * mm;
+  const double* __restrict__ Ee = B + lv.E + (long)e * mm;
+  {
+    double v1[BCR_EPT], v2[BCR_EPT], v3[BCR_EPT];
+#pragma unroll
+    for (int u = 0; u < BCR_EPT; ++u) {
+      const int w = tid + u * BCR_THREADS;
+      v1[u] = v2[u] = v3[u] = 0.0;
+      if (w < mm) {
+        if (ql >= 0) v1[u] = B[lv.Fb + (long)ql * mm + w];
+        if (qr >= 0) { v2[u] = B[lv.Fa + (long)qr * mm + w]; v3[u] = B[lv.Fb + (long)qr * mm + w]; }
+      }
+    }
+    double y1 = 0.0, y2 = 0.0;
+    if (tid < m) {
+      if (ql >= 0) y1 = B[lv.y + (long)ql * m + tid];
+      if (qr >= 0) y2 = B[lv.y + (long)qr * m + tid];
+    }
+#pragma unroll
+    for (int u = 0; u < BCR_EPT; ++u) {
+      const int w = tid + u * BCR_THREADS;
+      if (w < mm) {
+        const int r = w / m, c = w - r * m;
+        FbL[r * ld + c] = v1[u]; FaR[r * ld + c] = v2[u]; FbR[r * ld + c] = v3[u];
+      }
+    }
+    if (tid < m) { yL[tid] = y1; yR[tid] = y2; }
+  }
+  __syncthreads();
+  double* __restrict__ Dn = B + nx.D + (long)k * mm;
+  double* __restrict__ En = B + nx.E + (long)k * mm;
+  const bool copy_E = qr < 0;  // n odd, e = n - 1: blocks n - 1 and 0 stay coupled directly
+  const int h2 = m / 2;        // m is a multiple of 6: 2 x 2 tiles cover the block
+  for (int w = tid; w < h2 * h2; w += BCR_THREADS) {
+    const int tr = w / h2, tc = w - tr * h2, r = 2 * tr, c = 2 * tc;
+    const bool lower = tc <= tr;
+    const double *a1 = FbL + r * ld, *a1b = a1 + ld, *a2 = FaR + r * ld, *a2b = a2 + ld;
+    const double *b1 = FbL + c * ld, *b1b = b1 + ld, *b2 = FaR + c * ld, *b2b = b2 + ld, *b3 = FbR + c * ld, *b3b = b3 + ld;
+    double d00 = 0, d01 = 0, d10 = 0, d11 = 0, e00 = 0, e01 = 0, e10 = 0, e11 = 0;
+    if (lower) {
+      for (int t = 0; t < m; ++t) {
+        const double x1 = a1[t], x1b = a1b[t], x2 = a2[t], x2b = a2b[t];
+        const double p1 = b1[t], p1b = b1b[t], p2 = b2[t], p2b = b2b[t], p3 = b3[t], p3b = b3b[t];
+        d00 += x1 * p1 + x2 * p2; d01 += x1 * p1b + x2 * p2b; d10 += x1b * p1 + x2b * p2; d11 += x1b * p1b + x2b * p2b;
+        e00 += x2 * p3; e01 += x2 * p3b; e10 += x2b * p3; e11 += x2b * p3b;
+      }
+    } else {
+      for (int t = 0; t < m; ++t) {
+        const double x2 = a2[t], x2b = a2b[t], p3 = b3[t], p3b = b3b[t];
+        e00 += x2 * p3; e01 += x2 * p3b; e10 += x2b * p3; e11 += x2b * p3b;
+      }
+    }
+    const int o00 = r * m + c;
+    if (lower) {
+      const double n00 = De[o00] - d00, n01 = De[o00 + 1] - d01, n10 = De[o00 + m] - d10, n11 = De[o00 + m + 1] - d11;
+      Dn_s[r * ld + c] = n00; Dn_s[r * ld + c + 1] = n01; Dn_s[(r + 1) * ld + c] = n10; Dn_s[(r + 1) * ld + c + 1] = n11;
+    }
+    if (copy_E) { e00 = -Ee[o00]; e01 = -Ee[o00 + 1]; e10 = -Ee[o00 + m]; e11 = -Ee[o00 + m + 1]; }
+    En[o00] = -e00; En[o00 + 1] = -e01; En[o00 + m] = -e10; En[o00 + m + 1] = -e11;
+  }
+  for (int r = tid; r < m; r += BCR_THREADS) {
+    double s = 0.0;
+    for (int t = 0; t < m; ++t) s += FbL[r * ld + t] * yL[t] + FaR[r * ld + t] * yR[t];
+    B[nx.r + (long)k * m + r] = B[lv.r + (long)e * m + r] - s;
+  }
+  __syncthreads();
+  for (int w = tid; w < mm; w += BCR_THREADS) {  // lower triangle (and the 2 x 2 tiles on the diagonal) mirrored
+    const int r = w / m, c = w - r * m;
+    Dn[w] = (c <= r || (c == r + 1 && (r & 1) == 0)) ? Dn_s[r * ld + c] : Dn_s[c * ld + r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_bcr_backsolve: one workgroup per eliminated block i of a level: x_i = L^-T (y - Fa^T x_{i-1} - Fb^T x_{i+1}); x of
+// the even neighbours is already in X (indexed by the level-0 block: block i of level l is block i << l of level 0).
+// Also scatters x_i to the camera step dc ([Cf][6]; cam0[blk] = first free camera of a level-0 block, cnt[blk] its
+// camera count).  The three factor blocks come in with one round of loads.
+__global__ __launch_bounds__(BCR_THREADS) void k_bcr_backsolve(double* __restrict__ B, BcrPlan plan, int level,
+                                                               const int* __restrict__ cam0, const int* __restrict__ cnt,
+                                                               const LmCtrl* ctrl, double* __restrict__ dc) {
+  __shared__ double sF[3 * BCR_MAX_M * (BCR_MAX_M + 1)];
+  __shared__ double xa[BCR_MAX_M], xb[BCR_MAX_M], tt[BCR_MAX_M], part[4][BCR_MAX_M];
+  if (ctrl && ctrl->done) return;
+  const BcrLevel lv = plan.lv[level];
+  const int m = plan.m, ld = m + 1, mm = m * m, tid = threadIdx.x;
+  const int q = blockIdx.x, n = lv.n;
+  const int i = n == 1 ? 0 : 2 * q + 1;
+  const long o = (long)i << level;
+  double* __restrict__ X = B + plan.X;
+  double* sFa = sF;
+  double* sFb = sFa + m * ld;
+  double* sLi = sFb + m * ld;
+  {
+    double v1[BCR_EPT], v2[BCR_EPT], v3[BCR_EPT];
+#pragma unroll
+    for (int u = 0; u < BCR_EPT; ++u) {
+      const int w = tid + u * BCR_THREADS;
+      v1[u] = v2[u] = v3[u] = 0.0;
+      if (w < mm) {
+        v1[u] = B[lv.Fa + (long)q * mm + w]; v2[u] = B[lv.Fb + (long)q * mm + w]; v3[u] = B[lv.LiT + (long)q * mm + w];
+      }
+    }
+    double va = 0.0, vb = 0.0, vy = 0.0;
+    if (tid < m) {
+      const long oa = n > 1 ? (long)(i - 1) << level : 0, ob = n > 2 ? (long)(i + 1 == n ? 0 : i + 1) << level : 0;
+      va = n > 1 ? X[oa * m + tid] : 0.0;
+      vb = n > 2 ? X[ob * m + tid] : 0.0;
+      vy = B[lv.y + (long)q * m + tid];
+    }
+#pragma unroll
+    for (int u = 0; u < BCR_EPT; ++u) {
+      const int w = tid + u * BCR_THREADS;
+      if (w < mm) {
+        const int r = w / m, c = w - r * m;
+        sFa[r * ld + c] = v1[u]; sFb[r * ld + c] = v2[u]; sLi[r * ld + c] = v3[u];
+      }
+    }
+    if (tid < m) { xa[tid] = va; xb[tid] = vb; tt[tid] = vy; }
+  }
+  __syncthreads();
+  // t_c = y_c - sum_r Fa[r][c] xa[r] + Fb[r][c] xb[r]: four row groups per column, folded in a fixed order
+  const int c = tid & 63, g = tid >> 6;
+  if (c < m) {
+    double s = 0.0;
+    for (int r = g; r < m; r += 4) s += sFa[r * ld + c] * xa[r] + sFb[r * ld + c] * xb[r];
+    part[g][c] = s;
+  }
+  __syncthreads();
+  if (tid < m) tt[tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+  __syncthreads();
+  if (tid < m) {
+    double x = 0.0;
+    for (int cc = tid; cc < m; ++cc) x += sLi[tid * ld + cc] * tt[cc];
+    X[o * m + tid] = x;
+    if (tid < 6 * cnt[o]) dc[6L * cam0[o] + tid] = x;
+  }
+}

@@ -5,6 +5,7 @@
 #include "ba_kernels.h"
 #include "ba_dense.h"
 #include "ba_banded.h"
+#include "ba_bcr.h"
 
 #include <algorithm>
 #include <chrono>
@@ -113,6 +114,7 @@ struct ba_handle {
   std::vector<int> urow_ptr, ucol;
   std::vector<uint8_t> fixed;
   int g_lin = 16, g_schur = 64, lpg_lin = 1, lpg_schur = 1, lpg_back = 1;
+  long contrib_rows = 0;  // rows of the contribution tiles that k_schur_staged writes per launch
   int lin_cpw = 0;  // 1: k_linearize_flat (one chunk of whole tracks per wave) replaces k_linearize<G>
   int schur_cpb = 0;  // > 0: k_schur_staged with this many chunks per block
   bool small_solve = false;
@@ -134,6 +136,19 @@ struct ba_handle {
   double* bseg_x2 = nullptr;
   std::vector<BandedSeg> h_segs; std::vector<long> h_dst, h_rdst, h_cdst, h_crdst; std::vector<unsigned char> h_tr, h_ctr;
   std::vector<int> h_l2;
+  // block cyclic reduction of a trajectory's reduced system (ba_bcr.h)
+  bool bcr_solve = false;
+  BcrPlan bcr_plan{};
+  double* bcr_B = nullptr;
+  size_t bcr_zero = 0;  // doubles of the level-0 arrays (cleared before every assembly)
+  size_t bcr_lds_factor = 0, bcr_lds_update = 0;
+  const long *bcr_dst = nullptr, *bcr_dst2 = nullptr, *bcr_rdst = nullptr, *bcr_pad = nullptr;
+  const unsigned char* bcr_kind = nullptr;
+  const int *bcr_cam0 = nullptr, *bcr_cnt = nullptr;
+  int bcr_npad = 0;
+  std::vector<long> h_bdst, h_bdst2, h_brdst, h_bpad;
+  std::vector<unsigned char> h_bkind;
+  std::vector<int> h_bcam0, h_bcnt;
   double* dense_A = nullptr;
   int dense_nt = 0;
   size_t small_lds = 0;
@@ -155,8 +170,8 @@ struct ba_handle {
   LmMirror* mirror = nullptr;   // pinned, written by k_lm_decide
   LmMirror* mirror_dev = nullptr;
   std::vector<Span> spans;
-  double ktime_ms[BA_KERNEL_CLASSES] = {0, 0, 0, 0, 0, 0};
-  int kcount[BA_KERNEL_CLASSES] = {0, 0, 0, 0, 0, 0};
+  double ktime_ms[BA_KERNEL_CLASSES] = {};
+  int kcount[BA_KERNEL_CLASSES] = {};
 
   // multi-GPU: landmark-sharded ranks, one RCCL communicator (ba_comm_init)
   Rccl* rccl = nullptr;
@@ -189,7 +204,8 @@ int fail(ba_handle* h, int code, const char* fmt, ...) {
                   #expr, hipGetErrorString(e_));                                                \
   } while (0)
 
-enum { KT_LIN = 0, KT_SCHUR, KT_BACKSUB, KT_COST, KT_PCG, KT_OTHER };
+enum { KT_LIN = 0, KT_SCHUR, KT_BACKSUB, KT_COST, KT_PCG, KT_OTHER, KT_GATHER, KT_DECIDE };
+static_assert(KT_DECIDE + 1 == BA_KERNEL_CLASSES, "kernel classes");
 
 #define NCCL_TRY(h, expr)                                                                              \
   do {                                                                                                 \
@@ -440,14 +456,31 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
   // the gather also inverts the damped diagonal blocks when they are final there (one GPU, one-workgroup PCG)
   const int fused_precond = h->schur_cpb > 0 && h->world == 1 && h->small_solve;
   if (h->schur_cpb > 0)
-    launch_timed(h, KT_OTHER, k_gather_S, d.nu + (d.C - d.Cf), 256, d, mode, lam, o.min_diag, fused_precond);
-  else launch_timed(h, KT_OTHER, k_reduce_S, grid_for(d.s_slab_stride + 27L * d.C), 256, d, mode);
+    launch_timed(h, KT_GATHER, k_gather_S, d.nu + (d.C - d.Cf), 256, d, mode, lam, o.min_diag, fused_precond);
+  else launch_timed(h, KT_GATHER, k_reduce_S, grid_for(d.s_slab_stride + 27L * d.C), 256, d, mode);
   const size_t red_count = (size_t)d.nu * 36 + (size_t)6 * d.Cf + (size_t)27 * d.C;
   if (h->world > 1)  // the one exchange step of the path: partial S, reduced rhs, U / gc summed over the shards
     NCCL_TRY(h, h->rccl->AllReduce(d.S, d.S, red_count, ncclDouble, ncclSum, h->comm, h->stream));
   const double tol2 = o.pcg_tol * o.pcg_tol;
   if (h->comp_solve) {
     launch_timed_lds(h, KT_PCG, k_solve_components, d.n_comp, 64, h->comp_lds, d, lam, o.min_diag);
+    *pcg_iters = -1;
+    return BA_OK;
+  }
+  if (h->bcr_solve) {
+    const LmCtrl* ctrl = mode ? d.ctrl : nullptr;
+    const BcrPlan& pl = h->bcr_plan;
+    double* B = h->bcr_B;
+    HIP_TRY(h, hipMemsetAsync(B, 0, h->bcr_zero * sizeof(double), h->stream));
+    launch_timed(h, KT_PCG, k_bcr_assemble, grid_for((long)d.nu * 36 + 6L * d.Cf + h->bcr_npad), 256, d, B, pl.m, h->bcr_dst,
+                 h->bcr_dst2, h->bcr_kind, h->bcr_rdst, h->bcr_pad, h->bcr_npad, lam, o.min_diag, mode);
+    for (int l = 0; l < pl.n_levels; ++l) {
+      launch_timed_lds(h, KT_PCG, k_bcr_factor, pl.lv[l].n_elim, BCR_THREADS, h->bcr_lds_factor, B, pl, l, ctrl, d.scal + SC_BADV);
+      if (l + 1 < pl.n_levels)
+        launch_timed_lds(h, KT_PCG, k_bcr_update, pl.lv[l + 1].n, BCR_THREADS, h->bcr_lds_update, B, pl, l, ctrl);
+    }
+    for (int l = pl.n_levels - 1; l >= 0; --l)
+      launch_timed(h, KT_PCG, k_bcr_backsolve, pl.lv[l].n_elim, BCR_THREADS, B, pl, l, h->bcr_cam0, h->bcr_cnt, ctrl, d.dc);
     *pcg_iters = -1;
     return BA_OK;
   }
@@ -628,14 +661,15 @@ int lm_solve(ba_handle* h, ba_report* rep) {
   }
 
   const int check_every =
-      (h->small_solve || h->comp_solve || h->dense_solve || h->banded_solve) ? std::max(1, o.lm_check_every) : 1;
+      (h->small_solve || h->comp_solve || h->dense_solve || h->banded_solve || h->bcr_solve) ? std::max(1, o.lm_check_every) : 1;
   h->mirror->seq = 0;
   int enq = 0, rc;
   bool done = false;
   // On the staged path with a solver that keeps no state in the scalar block, the accumulators clean themselves
   // (k_gather_S zeroes the U / gc slabs it has summed, k_lm_decide the statistics it has folded): one memset per
   // solve instead of one per iteration.
-  const bool self_cleaning = h->schur_cpb > 0 && (h->small_solve || h->comp_solve || h->dense_solve || h->banded_solve);
+  const bool self_cleaning =
+      h->schur_cpb > 0 && (h->small_solve || h->comp_solve || h->dense_solve || h->banded_solve || h->bcr_solve);
   while (!done && enq < o.max_iters) {
     const int nb = std::min(check_every, o.max_iters - enq);
     for (int i = 0; i < nb; ++i, ++enq) {
@@ -652,9 +686,9 @@ int lm_solve(ba_handle* h, ba_report* rep) {
         k_fold_scalars<<<1, 128, 0, h->stream>>>(d, h->scal_fold, h->rank, h->world); note_launch(h);
         NCCL_TRY(h, h->rccl->AllReduce(h->scal_fold, h->scal_fold, (size_t)SC_COUNT + h->world, ncclDouble, ncclSum,
                                        h->comm, h->stream));
-        launch_timed(h, KT_OTHER, k_lm_decide, 1, 256, d, (const double*)h->scal_fold, h->world, h->mirror_dev, enq + 1);
+        launch_timed(h, KT_DECIDE, k_lm_decide, 1, 256, d, (const double*)h->scal_fold, h->world, h->mirror_dev, enq + 1);
       } else {
-        launch_timed(h, KT_OTHER, k_lm_decide, 1, 256, d, (const double*)nullptr, 1, h->mirror_dev, enq + 1);
+        launch_timed(h, KT_DECIDE, k_lm_decide, 1, 256, d, (const double*)nullptr, 1, h->mirror_dev, enq + 1);
       }
     }
     // k_lm_decide stores the control head into pinned host memory and then raises seq: spin on it (a copy +
@@ -835,7 +869,21 @@ int ba_comm_init(ba_handle* h, int32_t rank, int32_t world, const char* id128) {
 int ba_reduced_solver(const ba_handle* h, int32_t* kind) {
   if (!h || !kind) return BA_ERR_INVALID;
   if (!h->has_problem) return BA_ERR_STATE;
-  *kind = h->comp_solve ? 4 : h->banded_solve ? 3 : h->dense_solve ? 2 : h->small_solve ? 1 : 0;
+  *kind = h->bcr_solve ? 5 : h->comp_solve ? 4 : h->banded_solve ? 3 : h->dense_solve ? 2 : h->small_solve ? 1 : 0;
+  return BA_OK;
+}
+
+int ba_problem_info(const ba_handle* h, int64_t* info) {
+  if (!h || !info) return BA_ERR_INVALID;
+  if (!h->has_problem) return BA_ERR_STATE;
+  const int64_t rows = h->schur_cpb > 0 && h->d.n_chunks > 0 ? (int64_t)h->contrib_rows : 0;
+  const int64_t v[BA_INFO_COUNT] = {h->d.nu, rows, h->d.n_chunks, h->d.nslab_u,
+                                    h->bcr_solve ? 5 : h->comp_solve ? 4 : h->banded_solve ? 3 : h->dense_solve ? 2 : h->small_solve ? 1 : 0,
+                                    h->bcr_solve ? h->bcr_plan.m / 6 : h->banded_solve ? h->bshape.bw : 0,
+                                    h->bcr_solve ? h->bcr_plan.n_levels : h->banded_solve ? h->bshape.na : 0,
+                                    h->bcr_solve ? h->bcr_plan.N : h->bseg_P,
+                                    h->Cf, h->L_obs, h->lin_cpw > 0 ? 1 : 0, h->d.n_comp};
+  for (int i = 0; i < BA_INFO_COUNT; ++i) info[i] = v[i];
   return BA_OK;
 }
 
@@ -1183,6 +1231,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
       const long max_rows = ((long)env_int("BA_CONTRIB_MAX_MB", 16384) << 20) / (CTR_ROW * (long)sizeof(double));
       if (contrib_rows <= std::min<long>(max_rows, ((long)1 << 31) - 128)) {
         h->schur_cpb = cpb;
+        h->contrib_rows = contrib_rows;
         h->g_schur = G;
         h->d.n_chunks = n_chunks;
         for (auto& c : contributors) ctr_ptr[c.first + 1]++;
@@ -1414,6 +1463,93 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
     } else if (want == BA_SOLVER_BANDED_CHOLESKY) {
       return fail(h, BA_ERR_INVALID, "the banded Cholesky solver needs one connected problem with free cameras");
     }
+    // ---- block cyclic reduction (ba_bcr.h): super-blocks of >= bwr consecutive cameras make S block tridiagonal (cyclic)
+    h->bcr_solve = false;
+    if (Cf > 0 && !h->comp_solve && (want == BA_SOLVER_CYCLIC_REDUCTION || (want == BA_SOLVER_AUTO && h->banded_solve)) &&
+        env_int("BA_BCR", 1)) {
+      int bwr = 0;
+      for (int s2 = 0; s2 < nu; ++s2) bwr = std::max(bwr, std::min(ucol[s2] - urow[s2], Cf - (ucol[s2] - urow[s2])));
+      const int g = std::max(bwr, 1), N = Cf / g;
+      bool ok = N >= 3;
+      int maxsz = 0;
+      std::vector<int> start(std::max(N, 1) + 1, 0), sb_of(Cf, 0);
+      if (ok) {
+        for (int i2 = 0; i2 <= N; ++i2) start[i2] = (int)((long)i2 * Cf / N);
+        for (int i2 = 0; i2 < N; ++i2) {
+          maxsz = std::max(maxsz, start[i2 + 1] - start[i2]);
+          for (int f = start[i2]; f < start[i2 + 1]; ++f) sb_of[f] = i2;
+        }
+        ok = 6 * maxsz <= BCR_MAX_M;
+      }
+      if (want == BA_SOLVER_AUTO && N < 8) ok = false;  // few blocks: the other solvers are as fast
+      if (ok) {
+        const int m = 6 * maxsz;
+        const long mm = (long)m * m;
+        BcrPlan pl{};
+        pl.m = m; pl.N = N;
+        long off = 0;
+        int n_l = N, nl = 0;
+        // level-0 arrays first and contiguous: one memset clears them
+        std::vector<int> ns;
+        for (int t = N;; t = (t + 1) / 2) { ns.push_back(t); if (t == 1) break; }
+        ok = (int)ns.size() <= BCR_MAX_LEVELS;
+        if (ok) {
+          for (size_t l = 0; l < ns.size(); ++l) {
+            BcrLevel& lv = pl.lv[l];
+            lv.n = ns[l]; lv.n_elim = ns[l] == 1 ? 1 : ns[l] / 2;
+            lv.D = off; off += lv.n * mm;
+            lv.E = off; off += lv.n * mm;
+            lv.r = off; off += (long)lv.n * m;
+            if (l == 0) h->bcr_zero = (size_t)off;
+          }
+          for (size_t l = 0; l < ns.size(); ++l) {
+            BcrLevel& lv = pl.lv[l];
+            lv.LiT = off; off += lv.n_elim * mm;
+            lv.Fa = off; off += lv.n_elim * mm;
+            lv.Fb = off; off += lv.n_elim * mm;
+            lv.y = off; off += (long)lv.n_elim * m;
+          }
+          pl.X = off; off += (long)N * m;
+          pl.n_levels = (int)ns.size();
+          (void)n_l; (void)nl;
+          // where every upper block of S goes
+          h->h_bdst.assign(nu, 0); h->h_bdst2.assign(nu, 0); h->h_bkind.assign(nu, 0); h->h_brdst.assign(Cf, 0);
+          for (int s2 = 0; s2 < nu && ok; ++s2) {
+            const int r = urow[s2], c = ucol[s2], R = sb_of[r], Cc = sb_of[c];
+            const long lr = 6L * (r - start[R]), lc = 6L * (c - start[Cc]);
+            if (r == c) { h->h_bkind[s2] = 0; h->h_bdst[s2] = pl.lv[0].D + R * mm + lr * m + lr; }
+            else if (R == Cc) {
+              h->h_bkind[s2] = 1;
+              h->h_bdst[s2] = pl.lv[0].D + R * mm + lr * m + lc;
+              h->h_bdst2[s2] = pl.lv[0].D + R * mm + lc * m + lr;
+            } else if (Cc == R + 1) { h->h_bkind[s2] = 2; h->h_bdst[s2] = pl.lv[0].E + R * mm + lr * m + lc; }
+            else if (R == 0 && Cc == N - 1) { h->h_bkind[s2] = 3; h->h_bdst[s2] = pl.lv[0].E + (long)(N - 1) * mm + lc * m + lr; }
+            else ok = false;  // a coupling beyond the neighbouring super-block
+          }
+        }
+        if (ok) {
+          for (int f = 0; f < Cf; ++f) h->h_brdst[f] = pl.lv[0].r + (long)sb_of[f] * m + 6L * (f - start[sb_of[f]]);
+          h->h_bpad.clear(); h->h_bcam0.assign(N, 0); h->h_bcnt.assign(N, 0);
+          for (int i2 = 0; i2 < N; ++i2) {
+            h->h_bcam0[i2] = start[i2]; h->h_bcnt[i2] = start[i2 + 1] - start[i2];
+            for (int e = 6 * h->h_bcnt[i2]; e < m; ++e) h->h_bpad.push_back(pl.lv[0].D + i2 * mm + (long)e * m + e);
+          }
+          h->bcr_npad = (int)h->h_bpad.size();
+          h->bcr_plan = pl;
+          h->bcr_solve = true;
+          h->bcr_lds_factor = (size_t)(4 * m + 1) * (m + 1) * sizeof(double);
+          h->bcr_lds_update = ((size_t)4 * m * (m + 1) + 2 * m) * sizeof(double);
+          HIP_TRY(h, hipFuncSetAttribute((const void*)k_bcr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bcr_lds_factor));
+          HIP_TRY(h, hipFuncSetAttribute((const void*)k_bcr_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bcr_lds_update));
+          h->banded_solve = false; h->bseg_P = 0; h->dense_solve = false; h->small_solve = false;
+        }
+      }
+      if (!h->bcr_solve && want == BA_SOLVER_CYCLIC_REDUCTION)
+        return fail(h, BA_ERR_INVALID, "cyclic reduction needs a trajectory: cameras that share landmarks only with their "
+                                       "neighbours (at most %d apart), at least 3 groups of them", BCR_MAX_M / 6 - 1);
+    } else if (want == BA_SOLVER_CYCLIC_REDUCTION) {
+      return fail(h, BA_ERR_INVALID, "cyclic reduction needs one connected problem with free cameras");
+    }
     if (h->comp_solve || h->dense_solve) h->small_solve = false;
     h->dense_nt = (6 * Cf + DT - 1) / DT;
     if (h->comp_solve && h->comp_lds > 32 * 1024)
@@ -1490,6 +1626,16 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
       return rc;
   } else if (h->banded_solve && (rc = dev_alloc(h, &h->banded_B, (size_t)Cf * h->bshape.nrow * 36))) {
     return rc;
+  }
+  h->bcr_B = nullptr;
+  if (h->bcr_solve) {
+    const BcrPlan& pl = h->bcr_plan;
+    const size_t total = (size_t)pl.X + (size_t)pl.N * pl.m;
+    if ((rc = dev_alloc(h, &h->bcr_B, total)) || (rc = dev_upload(h, &h->bcr_dst, h->h_bdst)) ||
+        (rc = dev_upload(h, &h->bcr_dst2, h->h_bdst2)) || (rc = dev_upload(h, &h->bcr_kind, h->h_bkind)) ||
+        (rc = dev_upload(h, &h->bcr_rdst, h->h_brdst)) || (rc = dev_upload(h, &h->bcr_pad, h->h_bpad)) ||
+        (rc = dev_upload(h, &h->bcr_cam0, h->h_bcam0)) || (rc = dev_upload(h, &h->bcr_cnt, h->h_bcnt)))
+      return rc;
   }
   h->dense_A = nullptr;
   if (h->dense_solve) {
@@ -1787,7 +1933,7 @@ int ba_debug_linearization(ba_handle* h, const double* poses, const double* poin
   }
   if (S) {
     if ((rc = fetch(t, d.S, (size_t)36 * d.nu))) return rc;
-    if (h->small_solve || h->comp_solve || h->dense_solve || h->banded_solve) {  // these solvers apply the damping on the fly; add it for the export
+    if (h->small_solve || h->comp_solve || h->dense_solve || h->banded_solve || h->bcr_solve) {  // these solvers apply the damping on the fly; add it for the export
       std::vector<double> ugc, ud((size_t)6 * Cf);
       if ((rc = fetch(ugc, d.Ugc, (size_t)27 * C))) return rc;
       for (int f = 0; f < Cf; ++f)

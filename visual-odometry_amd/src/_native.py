@@ -83,6 +83,7 @@ _SIGNATURES = {
     "ba_debug_linearization": (C.c_int, [_P, _D, _D, C.c_double] + [_D] * 9),
     "ba_reduced_solver": (C.c_int, [_P, _I]),
     "ba_schur_block_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "ba_problem_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "ba_get_kernel_times": (C.c_int, [_P, _D, _I]),
     "ba_set_kernel_timing": (C.c_int, [_P, C.c_int32]),
     "ba_comm_unique_id": (C.c_int, [C.c_char_p]),
@@ -339,23 +340,32 @@ class Solver:
                                                                 ("U", "V", "W", "gc", "gp", "S", "rhs", "dc", "dp")]))
         return out
 
-    KERNEL_CLASSES = ("k_linearize", "k_schur", "k_backsub", "k_cost", "pcg", "other")
+    KERNEL_CLASSES = ("k_linearize", "k_schur", "k_backsub", "k_cost", "pcg", "other", "k_gather_S", "k_lm_decide")
 
     def kernel_times(self) -> dict:
-        ms = np.zeros(6)
-        cnt = np.zeros(6, dtype=np.int32)
+        ms = np.zeros(8)
+        cnt = np.zeros(8, dtype=np.int32)
         self._check(self._lib.ba_get_kernel_times(self._h, _dptr(ms), cnt.ctypes.data_as(_I)))
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KERNEL_CLASSES)}
 
     def set_kernel_timing(self, on: bool):
         self._check(self._lib.ba_set_kernel_timing(self._h, 1 if on else 0))
 
-    REDUCED_SOLVERS = ("pcg", "pcg_one_workgroup", "dense_cholesky", "banded_cholesky", "component_cholesky")
+    REDUCED_SOLVERS = ("pcg", "pcg_one_workgroup", "dense_cholesky", "banded_cholesky", "component_cholesky",
+                       "cyclic_reduction")
 
     def reduced_solver(self) -> str:
         v = C.c_int32()
         self._check(self._lib.ba_reduced_solver(self._h, C.byref(v)))
         return self.REDUCED_SOLVERS[v.value]
+
+    INFO_KEYS = ("s_blocks", "contrib_rows", "schur_chunks", "u_slabs", "reduced_solver", "band_bw", "band_arrow",
+                 "band_segments", "free_cameras", "observed_landmarks", "linearize_flat", "components")
+
+    def problem_info(self) -> dict:
+        v = (C.c_int64 * 12)()
+        self._check(self._lib.ba_problem_info(self._h, v))
+        return {k: int(v[i]) for i, k in enumerate(self.INFO_KEYS)}
 
     def schur_block_count(self) -> int:
         v = C.c_int64()
