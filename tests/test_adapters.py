@@ -113,3 +113,51 @@ def test_bal_problem_solves_like_the_original(tmp_path):
             costs.append(s.solve(poses, pts)[2])
     assert abs(costs[0]["cost0"] - costs[1]["cost0"]) <= 1e-9 * costs[0]["cost0"]
     assert abs(costs[0]["cost"] - costs[1]["cost"]) <= 1e-8 * costs[0]["cost"]
+
+
+@pytest.mark.gpu
+def test_adapter_fed_solves_match_the_oracle(golden, tmp_path):
+    """Oracle legs for the adapters: the scene goes in through the second container family (ImageObservations ->
+    ImageFeatures -> BundleAdjustment.optimize) and through a BAL file (write_bal -> read_bal -> the C ABI); both
+    converged costs against the polished minimum the fixture recorded from the reference path and against the numpy
+    LM run on the arrays the adapter produced (1e-6 relative)."""
+    from oracle import lm_schur_numpy as lm
+    from src import _native
+    from src.bundle_adjustment import BundleAdjustment
+    from src.camera import PinHoleCamera
+    from src.camera_pose import CameraPose
+    from src.feature_observation import Landmarks3D
+
+    g = golden("noisy_10x300")
+    n_poses = len(g["poses_gt"]) - 1
+    poses = np.vstack([g["pose0"][None], g["x0"][: 7 * n_poses].reshape(-1, 7)])
+    pts = g["x0"][7 * n_poses:].reshape(-1, 3)
+    pol = float(g["polished_cost"])
+    # (1) frames of FeatureObservation objects, shuffled inside every frame
+    rng = np.random.default_rng(1)
+    frames = []
+    for c in range(n_poses + 1):
+        sel = np.flatnonzero(g["obs_cam"] == c)
+        rng.shuffle(sel)
+        frames.append(ad.ImageObservations(c, float(c), [ad.FeatureObservation(int(g["landmark_ids"][g["obs_pt"][k]]),
+                                                                                g["obs_uv"][k], c, float(c)) for k in sel]))
+    feats = ad.image_features_from_observations(frames)
+    cam = PinHoleCamera.from_vector(np.array([float(v) for v in g["intr"]]))
+    ba = BundleAdjustment()
+    _, lms, out_poses = ba.optimize(feats, CameraPose(poses[0, :3], poses[0, 3:7], 0.0), cam,
+                                    [CameraPose(p[:3], p[3:7], float(i + 1)) for i, p in enumerate(poses[1:])],
+                                    Landmarks3D(pts, g["landmark_ids"]))
+    assert abs(ba.last_report["cost"] - pol) <= 1e-6 * pol
+    oc, op, uv = ad.pack_image_features(feats, g["landmark_ids"])
+    o = lm.lm_solve(poses, pts, oc, op, uv, g["intr"])[2]
+    assert abs(ba.last_report["cost"] - o.cost) <= 1e-6 * o.cost
+    # (2) a BAL file of the same problem (BAL's camera convention: the adapter converts poses and pixels both ways)
+    path = str(tmp_path / "noisy.txt")
+    ad.write_bal(path, poses, pts, g["obs_cam"], g["obs_pt"], g["obs_uv"], g["intr"])
+    b = ad.read_bal(path)
+    with _native.Solver() as s:
+        s.set_problem(n_poses + 1, len(pts), b["obs_cam"], b["obs_pt"], b["obs_uv"], b["intr"])
+        rep = s.solve(b["poses"], b["points"])[2]
+    ob = lm.lm_solve(b["poses"], b["points"], b["obs_cam"], b["obs_pt"], b["obs_uv"], b["intr"])[2]
+    assert abs(rep["cost0"] - ob.cost0) <= 1e-9 * ob.cost0
+    assert abs(rep["cost"] - ob.cost) <= 1e-6 * ob.cost and abs(rep["cost"] - pol) <= 1e-6 * pol

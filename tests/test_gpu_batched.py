@@ -214,3 +214,30 @@ def test_banded_cholesky_on_a_small_dense_pattern(golden):
             s.set_problem(2, len(pts), g["obs_cam"][two], g["obs_pt"][two], g["obs_uv"][two], g["intr"])
             costs.append(s.solve(poses[:2], pts)[2]["cost"])
     assert abs(costs[0] - costs[1]) <= 1e-8 * costs[0]
+
+
+def test_batched_at_config5_size():
+    """BASELINE configs[4] at its stated size: 1024 windows of 10 keyframes x 100 landmarks (1 024 000 observations) in
+    one call.  Every window: its cost fell, is 0.5 |r|^2 of its own residuals, sits at the noise level (0.5 px per
+    axis), first keyframe untouched; a sample of windows against the oracle's LM run on that window alone (1e-6 in
+    cost: the windows share one damping sequence and one termination test, so each must still reach its own minimum)."""
+    B, L = 1024, 100
+    probs, scs = zip(*[_window(s, L=L) for s in range(B)])
+    intr = scs[0]["intr"]
+    with _native.Solver() as s:
+        P, X, cost0, cost, rep = s.solve_batched(probs, intr)
+        assert s.reduced_solver() == "component_cholesky"
+    assert rep["status"] in (1, 2, 3) and rep["bad_pivots"] == 0
+    assert rep["nobs"] == B * 10 * L
+    assert abs(cost.sum() - rep["cost"]) <= 1e-10 * rep["cost"]
+    assert np.all(cost < cost0)
+    rms = np.sqrt(2 * cost / (10 * L))
+    assert np.all((rms > 0.55) & (rms < 0.80)), (rms.min(), rms.max())
+    for b in range(0, B, 97):
+        np.testing.assert_array_equal(P[b][0], np.asarray(probs[b]["poses"])[0])
+    for b in (0, 333, 700, 1023):
+        p = probs[b]
+        o = lm.lm_solve(np.asarray(p["poses"]), np.asarray(p["points"]), p["obs_cam"], p["obs_pt"], p["obs_uv"], intr)[2]
+        assert abs(cost[b] - o.cost) <= 1e-6 * o.cost, (b, cost[b], o.cost)
+    print(f"1024 windows: {rep['solve_ms']:.2f} ms, {rep['iterations']} LM iterations, "
+          f"{1e3 * rep['solve_ms'] / B:.2f} us per window")

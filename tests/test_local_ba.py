@@ -55,6 +55,7 @@ def test_window_construction():
 
 @pytest.mark.gpu
 def test_batched_windows_match_individual_solves():
+    from oracle import lm_schur_numpy as lm
     from src import _native
 
     sc = scenes.ring_scene(20, 400, 5)
@@ -75,6 +76,11 @@ def test_batched_windows_match_individual_solves():
             s.set_problem(10, len(w.landmark_ids), w.obs_cam, w.obs_pt, w.obs_uv, sc["intr"])
             Pi, Xi, rep = s.solve(sc["poses_guess"][w.keyframes], sc["points_guess"][w.landmark_rows])
         assert abs(c1[b] - rep["cost"]) <= 1e-6 * rep["cost"], (b, c1[b], rep["cost"])
+        # ... and the ORACLE's LM (numpy, exact reduced solve) on that window alone: same minimum, 1e-6 in cost
+        o = lm.lm_solve(sc["poses_guess"][w.keyframes], sc["points_guess"][w.landmark_rows], w.obs_cam, w.obs_pt,
+                        w.obs_uv, sc["intr"], opt=lm.LMOptions(ftol=1e-13, max_iters=100))[2]
+        assert abs(c1[b] - o.cost) <= 1e-6 * o.cost, (b, c1[b], o.cost)
+        assert abs(c0[b] - o.cost0) <= 1e-12 * o.cost0
         # one fixed keyframe leaves the scale about its centre free: align it before comparing
         c = Pi[0, :3]
         A, B = pts[w.landmark_rows] - c, Xi - c
@@ -102,3 +108,12 @@ def test_overlapping_windows_and_two_fixed_keyframes():
     rms = np.sqrt(2 * c1 / np.array([len(w.obs_cam) for w in lba.last_windows]))
     # pixel noise is 0.5 px; two keyframes pinned at their noisy guesses (5 cm, 0.01 rad) cost the rest
     assert np.all(rms < 3.0)
+    # oracle leg: every window against the numpy LM with the same two keyframes held constant (1e-6 in cost)
+    from oracle import lm_schur_numpy as lm
+    for b, w in enumerate(lba.last_windows):
+        free = np.ones(len(w.keyframes), bool)
+        free[:2] = False
+        o = lm.lm_solve(sc["poses_guess"][w.keyframes], sc["points_guess"][w.landmark_rows], w.obs_cam, w.obs_pt,
+                        w.obs_uv, sc["intr"], free=free)[2]
+        assert abs(c0[b] - o.cost0) <= 1e-12 * o.cost0
+        assert abs(c1[b] - o.cost) <= 1e-6 * o.cost, (b, c1[b], o.cost)
