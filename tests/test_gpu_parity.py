@@ -342,3 +342,43 @@ def test_unstructured_visibility_matches_oracle():
         costs.append((rep["cost"], out["S"], out["rhs"]))
     np.testing.assert_allclose(costs[0][1], costs[1][1], rtol=0, atol=1e-10 * np.abs(costs[1][1]).max())
     np.testing.assert_allclose(costs[0][2], costs[1][2], rtol=0, atol=1e-10 * np.abs(costs[1][2]).max())
+
+
+def test_run_to_run_determinism_of_the_cost():
+    """the only run-to-run noise is the arrival order of the fp64 atomics that fold U / g_c and the
+    scalar statistics (S, the Cholesky solvers and the landmark blocks are summed in a fixed order): N solves of one
+    problem in one process agree to 1e-12 relative in cost (and take the same iterations)."""
+    sc = scenes.ring_scene(50, 2000, 10)
+    C, L = len(sc["poses_guess"]), len(sc["points_guess"])
+    with _native.Solver() as s:
+        s.set_problem(C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+        s.upload_guess(sc["poses_guess"], sc["points_guess"])
+        reps = [s.solve_resident() for _ in range(8)]
+    costs = np.array([r["cost"] for r in reps])
+    assert (costs.max() - costs.min()) <= 1e-12 * costs.min(), costs
+    assert len({r["iterations"] for r in reps}) == 1 and len({r["status"] for r in reps}) == 1
+    assert np.ptp([r["cost0"] for r in reps]) <= 1e-13 * reps[0]["cost0"]
+
+
+def test_residual_function_callback_paths(golden):
+    """BundleAdjustment.residual_function as scipy would call it, repeatedly: the small problem goes through the
+    entry point that allocates nothing, a problem beyond its limits through one cached handle; both equal the
+    reference's recorded residuals / the oracle (1e-9 px)."""
+    from src.bundle_adjustment import BundleAdjustment
+    g = golden("noisy_10x300")
+    feats, pose0, cam, guesses, lms = scenes.to_containers(scenes.noisy_scene(10, 300))
+    n_poses = len(guesses)
+    for _ in range(3):
+        r = BundleAdjustment.residual_function(g["x0"], pose0, n_poses, g["landmark_ids"], feats, cam)
+        np.testing.assert_allclose(r, g["residual_at_x0"], rtol=0, atol=1e-9)
+    assert BundleAdjustment._residual_solver is None
+    big = scenes.ring_scene(40, 16000, 10)  # 160 000 observations > BA_STATIC_MAX_OBS
+    feats, pose0, cam, guesses, lms = scenes.to_containers(big)
+    ref = orc.residual_packed(big["x0"], big["pose0"], 39, big["obs_cam"], big["obs_pt"], big["obs_uv"], big["intr"])
+    for k in range(3):
+        x = big["x0"] + 1e-4 * k
+        r = BundleAdjustment.residual_function(x, pose0, 39, big["landmark_ids"], feats, cam)
+        if k == 0:
+            np.testing.assert_allclose(r, ref, rtol=0, atol=1e-9)
+            first = BundleAdjustment._residual_solver[1]
+    assert BundleAdjustment._residual_solver[1] is first  # one handle for the three calls

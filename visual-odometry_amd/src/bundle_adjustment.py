@@ -60,6 +60,8 @@ def _pose_rows(camera_pose_initial: CameraPose, poses: List[CameraPose]) -> np.n
 class BundleAdjustment:
     """Bundle adjustment of 3-D landmarks and camera poses (first pose fixed)."""
 
+    _residual_solver = None  # (key of the observations, Solver): residual_function's handle for large problems
+
     def __init__(self, **solver_options) -> None:
         # the reference constructor takes nothing (bundle_adjustment.py:15-16); options are an extension
         self.solver_options = solver_options
@@ -81,10 +83,23 @@ class BundleAdjustment:
         obs_cam, obs_pt, obs_uv = _pack_observations(observations, landmark_ids)
         poses = np.vstack([np.concatenate([camera_pose_initial.position, camera_pose_initial.quaternion])[None],
                            params[: 7 * num_poses].reshape(num_poses, 7)])
-        with _native.Solver() as s:
-            s.set_problem(num_poses + 1, L, obs_cam, obs_pt, obs_uv, camera_model.to_vector())
-            res, _, _ = s.evaluate(poses, params[7 * num_poses:].reshape(L, 3))
-        return res
+        points = params[7 * num_poses:].reshape(L, 3)
+        intr = camera_model.to_vector()
+        # scipy calls this tens of times per Jacobian: no handle, no sort, no allocation when the problem fits the
+        # library's static scratch (ba_evaluate_static); larger problems keep ONE handle for as long as the
+        # observations stay the same (ba_set_problem sorts and uploads them: once, not per call)
+        if _native.fits_static(num_poses + 1, L, len(obs_cam)):
+            return _native.evaluate_static(num_poses + 1, L, obs_cam, obs_pt, obs_uv, intr, poses, points)[0]
+        key = (num_poses + 1, L, hash(obs_cam.tobytes()), hash(obs_pt.tobytes()), hash(obs_uv.tobytes()),
+               hash(np.asarray(intr, dtype=np.float64).tobytes()))
+        cache = BundleAdjustment._residual_solver
+        if cache is None or cache[0] != key:
+            if cache is not None:
+                cache[1].close()
+            s = _native.Solver()
+            s.set_problem(num_poses + 1, L, obs_cam, obs_pt, obs_uv, intr)
+            BundleAdjustment._residual_solver = cache = (key, s)
+        return cache[1].evaluate(poses, points)[0]
 
     # ------------------------------------------------------------------ mask (reference :89-154)
     @staticmethod

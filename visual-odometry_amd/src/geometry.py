@@ -5,7 +5,7 @@ builders use.  Conventions are the reference's: quat
 ``[w, x, y, z]``, ``R(q)`` rotates camera -> world (geometry.py:192-213), Euler angles are
 ``[roll, pitch, yaw]`` composed as ``Rz @ Ry @ Rx`` (geometry.py:366-390).  The arithmetic order of
 every formula follows the reference so that scenes rebuilt here are bit-identical to scenes built
-with the reference (checked by tests/test_python_surface.py against tests/golden/).
+with the reference (checked by tests/test_scenes_golden.py against tests/golden/).
 """
 
 from typing import Tuple
