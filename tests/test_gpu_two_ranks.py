@@ -125,3 +125,13 @@ def test_invalid_input_on_one_rank_stops_every_rank(fault, stage, tmp_path):
         assert str(part["err"]) != ""
         assert abs(float(part["cost"]) - rep0["cost"]) <= 1e-8 * rep0["cost"]
     assert "another rank" in str(parts[0]["err"])
+
+
+def test_sharded_solve_with_several_iterations_per_host_poll(tmp_path):
+    """lm_check_every = 3 with two ranks: three LM iterations (each with its two all-reduces) are enqueued per host poll;
+    the iterations enqueued after the device-side termination exit at once on every rank, collectives included, so the
+    ranks stay in step and the result is the single-GPU one."""
+    sc = scenes.ring_scene(300, 3000, 6)
+    P0, X0, rep0 = single_gpu(sc, ftol=1e-12)
+    parts = run_ranks(2, "ring_long", tmp_path, ftol=1e-12, lm_check_every=3)
+    check_against_single(parts, sc, P0, X0, rep0, atol=1e-6)
