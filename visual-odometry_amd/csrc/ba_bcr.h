@@ -14,8 +14,10 @@
 //                   D'_{e/2} = D_e - Fb_{e-1} Fb_{e-1}^T - Fa_{e+1} Fa_{e+1}^T
 //                   E'_{e/2} = -Fa_{e+1} Fb_{e+1}^T            (= block (e, e + 2))
 //                   r'_{e/2} = r_e - Fb_{e-1} y_{e-1} - Fa_{e+1} y_{e+1}
-// until one block is left; then back up (k_bcr_backsolve): x_i = L^-T (y - Fa^T x_{i-1} - Fb^T x_{i+1}).
-// The chain is 2 ceil(log2 N) + 1 short kernels deep instead of hundreds of column steps, every level is as wide as
+// until two blocks (or BCR_TAIL_ROWS / m, if more) are left, which ONE workgroup factors as a dense matrix in LDS
+// (k_bcr_tail: the last two levels of ~28 us each collapse into one kernel); then back up (k_bcr_backsolve):
+// x_i = L^-T (y - Fa^T x_{i-1} - Fb^T x_{i+1}).
+// The chain is 3 log2(N m / BCR_TAIL_ROWS) + 2 short kernels deep instead of hundreds of column steps, every level is as wide as
 // the chip, and all sums run in a fixed order (no atomics): the step is bitwise reproducible, which the multi-GPU
 // solve relies on.  The elimination is a block Cholesky in nested-dissection order: Schur complements of an SPD
 // matrix, as stable as the banded factorisation it replaces.
@@ -28,16 +30,18 @@
 constexpr int BCR_THREADS = 256;
 constexpr int BCR_MAX_M = 48;      // 8 cameras per super-block
 constexpr int BCR_MAX_LEVELS = 24;
+constexpr int BCR_TAIL_ROWS = 64;   // the last max(2, BCR_TAIL_ROWS / m) blocks are solved densely by one workgroup (a step of its
+                                    // block Cholesky costs ~1 us at 60 rows but ~4 us at 120: larger tails lose to the levels they replace)
 
 struct BcrLevel {
   int n;        // blocks at this level
-  int n_elim;   // blocks eliminated here: the odd ones (n / 2), or the single block of the last level
+  int n_elim;   // blocks eliminated here: the odd ones (n / 2); 0 at the tail level (lv[n_levels])
   long D, E, r;            // offsets (doubles) of D [n][m*m], E [n][m*m], r [n][m]
   long LiT, Fa, Fb, y;     // offsets of the factors of the eliminated blocks [n_elim][...]
 };
 
 struct BcrPlan {
-  int m, n_levels, N;
+  int m, n_levels, N;      // n_levels elimination levels lv[0 .. n_levels); lv[n_levels] holds the tail system (D, E, r only)
   long X;                  // offset of x [N][m], indexed by the level-0 block
   BcrLevel lv[BCR_MAX_LEVELS];
 };
@@ -106,8 +110,7 @@ constexpr int BCR_EPT = (BCR_MAX_M * BCR_MAX_M + BCR_THREADS - 1) / BCR_THREADS;
 // update a thread takes one row and one 6-wide column block: 6 panel entries and a 6x6 block of L out of LDS for 36
 // multiply-adds): what is left below D_i is Fa = E_{i-1} L^-T, Fb = E_i^T L^-T, L^-T and y^T = (L^-1 r_i)^T.
 // All global loads are issued before the first use (one round trip, not one per loop iteration).
-//   n == 2: the two couplings of blocks 0 and 1 (E_0 and, around the loop, E_1) are one block: Ea = E_0 + E_1^T, Eb = 0
-//   n == 1: the last block, no neighbours
+// (Levels have n >= 3 blocks: smaller systems go to k_bcr_tail.)
 __global__ __launch_bounds__(BCR_THREADS) void k_bcr_factor(double* __restrict__ B, BcrPlan plan, int level, const LmCtrl* ctrl,
                                                             double* __restrict__ badv) {
   extern __shared__ double lds[];
@@ -116,25 +119,19 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_factor(double* __restrict__
   const int m = plan.m, ld = m + 1, mm = m * m, nb = m / 6;
   const int tid = threadIdx.x;
   const int q = blockIdx.x;                    // q-th eliminated block
-  const int i = lv.n == 1 ? 0 : 2 * q + 1;     // its index at this level
+  const int i = 2 * q + 1;                     // its index at this level
   const int R = 4 * m + 1;
   double* T = lds;                             // [R][ld]
   const double* __restrict__ Di = B + lv.D + (long)i * mm;
-  const bool has_nb = lv.n > 1;
-  const int ia = has_nb ? i - 1 : 0;
-  const double* __restrict__ Ea = B + lv.E + (long)ia * mm;   // block (i - 1, i)
-  const double* __restrict__ Eb = B + lv.E + (long)i * mm;    // block (i, i + 1)
-  const bool merged = lv.n == 2;
+  const double* __restrict__ Ea = B + lv.E + (long)(i - 1) * mm;   // block (i - 1, i)
+  const double* __restrict__ Eb = B + lv.E + (long)i * mm;         // block (i, i + 1)
   {
     double vd[BCR_EPT], va[BCR_EPT], vb[BCR_EPT];
 #pragma unroll
     for (int u = 0; u < BCR_EPT; ++u) {
       const int e = tid + u * BCR_THREADS;
       vd[u] = va[u] = vb[u] = 0.0;
-      if (e < mm) {
-        vd[u] = Di[e];
-        if (has_nb) { va[u] = Ea[e]; vb[u] = Eb[e]; }
-      }
+      if (e < mm) { vd[u] = Di[e]; va[u] = Ea[e]; vb[u] = Eb[e]; }
     }
     const double rv = tid < m ? B[lv.r + (long)i * m + tid] : 0.0;
 #pragma unroll
@@ -144,26 +141,8 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_factor(double* __restrict__
         const int r = e / m, c = e - r * m;
         T[r * ld + c] = vd[u];
         T[(3 * m + r) * ld + c] = r == c ? 1.0 : 0.0;
-        if (!merged) {
-          T[(m + r) * ld + c] = va[u];          // row r of block i - 1, column c of block i
-          T[(2 * m + c) * ld + r] = vb[u];      // E_i^T: E_i[r][c] is row c of block i + 1, column r of block i
-        } else {
-          T[(2 * m + r) * ld + c] = 0.0;
-        }
-      }
-    }
-    if (merged) {  // Ea = E_0 + E_1^T: two passes so that each entry has one writer at a time
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < BCR_EPT; ++u) {
-        const int e = tid + u * BCR_THREADS;
-        if (e < mm) { const int r = e / m, c = e - r * m; T[(m + r) * ld + c] = va[u]; }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < BCR_EPT; ++u) {
-        const int e = tid + u * BCR_THREADS;
-        if (e < mm) { const int r = e / m, c = e - r * m; T[(m + c) * ld + r] += vb[u]; }
+        T[(m + r) * ld + c] = va[u];          // row r of block i - 1, column c of block i
+        T[(2 * m + c) * ld + r] = vb[u];      // E_i^T: E_i[r][c] is row c of block i + 1, column r of block i
       }
     }
     if (tid < m) T[4 * m * ld + tid] = rv;
@@ -243,11 +222,8 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_update(double* __restrict__
   const int k = blockIdx.x, e = 2 * k, n = lv.n;
   // odd neighbours (indices into the factor arrays), -1: none
   int ql = -1, qr = -1;
-  if (n == 2) { qr = 0; }                                  // merged coupling lives in Fa of block 1
-  else {
-    if (e >= 1) ql = (e - 1) >> 1; else if ((n & 1) == 0) ql = (n - 1) >> 1;   // block 0's left neighbour is n - 1
-    if (e + 1 < n) qr = (e + 1) >> 1;
-  }
+  if (e >= 1) ql = (e - 1) >> 1; else if ((n & 1) == 0) ql = (n - 1) >> 1;   // block 0's left neighbour is n - 1
+  if (e + 1 < n) qr = (e + 1) >> 1;
   double* FbL = lds;                 // Fb of the left odd block  [m][ld]  (rows: block e)
   double* FaR = FbL + m * ld;        // Fa of the right odd block [m][ld]  (rows: block e)
   double* FbR = FaR + m * ld;        // Fb of the right odd block [m][ld]  (rows: block e + 2)
@@ -340,7 +316,7 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_backsolve(double* __restric
   const BcrLevel lv = plan.lv[level];
   const int m = plan.m, ld = m + 1, mm = m * m, tid = threadIdx.x;
   const int q = blockIdx.x, n = lv.n;
-  const int i = n == 1 ? 0 : 2 * q + 1;
+  const int i = 2 * q + 1;
   const long o = (long)i << level;
   double* __restrict__ X = B + plan.X;
   double* sFa = sF;
@@ -358,9 +334,9 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_backsolve(double* __restric
     }
     double va = 0.0, vb = 0.0, vy = 0.0;
     if (tid < m) {
-      const long oa = n > 1 ? (long)(i - 1) << level : 0, ob = n > 2 ? (long)(i + 1 == n ? 0 : i + 1) << level : 0;
-      va = n > 1 ? X[oa * m + tid] : 0.0;
-      vb = n > 2 ? X[ob * m + tid] : 0.0;
+      const long oa = (long)(i - 1) << level, ob = (long)(i + 1 == n ? 0 : i + 1) << level;
+      va = X[oa * m + tid];
+      vb = X[ob * m + tid];
       vy = B[lv.y + (long)q * m + tid];
     }
 #pragma unroll
@@ -390,4 +366,152 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_backsolve(double* __restric
     X[o * m + tid] = x;
     if (tid < 6 * cnt[o]) dc[6L * cam0[o] + tid] = x;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_bcr_tail: the last n <= max(2, BCR_TAIL_ROWS / m) blocks (level `plan.n_levels`), one workgroup: the cyclic block
+// tridiagonal system is laid out as ONE dense symmetric matrix of Nd = n m rows in LDS, with the right-hand side as row
+// Nd (lower triangle: D_i on the diagonal, E_i^T below it, the loop closure E_{n-1} in the corner; n == 2: both
+// couplings of blocks 0 and 1 land on the same block), factored by the block Cholesky loop of k_bcr_factor (the
+// right-hand-side row comes out as y = L^-1 r), then solved backwards column block by column block
+// (x_j = L_jj^-T y_j;  y_rho -= L[j][rho] x_j for the rows above).  Writes x of the tail blocks to X and to dc.
+__global__ __launch_bounds__(BCR_THREADS) void k_bcr_tail(double* __restrict__ B, BcrPlan plan, const int* __restrict__ cam0,
+                                                          const int* __restrict__ cnt, const LmCtrl* ctrl,
+                                                          double* __restrict__ dc, double* __restrict__ badv) {
+  extern __shared__ double lds[];
+  if (ctrl && ctrl->done) return;
+  const int level = plan.n_levels;
+  const BcrLevel lv = plan.lv[level];
+  const int m = plan.m, mm = m * m, n = lv.n, Nd = n * m, ld = Nd + 1, nb = Nd / 6, R = Nd + 1;
+  const int tid = threadIdx.x;
+  double* T = lds;                      // [R][ld]
+  double* sLi = T + (long)R * ld;       // [nb][36] inverses of the diagonal blocks of L
+  double* xs = sLi + nb * 36;           // [Nd]
+  for (int e = tid; e < R * ld; e += BCR_THREADS) T[e] = 0.0;
+  __syncthreads();
+  // D, E, r of the level: eight loads in flight per thread and round (a plain strided loop would wait for every
+  // load before issuing the next one: ~1 us a round)
+  constexpr int UN = 8;
+  for (int base = 0; base < n * mm; base += BCR_THREADS * UN) {
+    double v[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int e = base + u * BCR_THREADS + tid;
+      v[u] = e < n * mm ? B[lv.D + e] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int e = base + u * BCR_THREADS + tid;
+      if (e < n * mm) {
+        const int i = e / mm, w = e - i * mm, r = w / m, c = w - r * m;
+        if (c <= r) T[(i * m + r) * ld + i * m + c] = v[u];
+      }
+    }
+  }
+  for (int e = tid; e < Nd; e += BCR_THREADS) T[Nd * ld + e] = B[lv.r + e];
+  if (n >= 2) {
+    // E_i = block (i, i + 1): its transpose is the lower block (i + 1, i); the last one, block (n - 1, 0), is lower as
+    // it is (n == 2: it lands on the block that E_0^T fills, hence the barrier and the +=)
+    for (int base = 0; base < (n - 1) * mm; base += BCR_THREADS * UN) {
+      double v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int e = base + u * BCR_THREADS + tid;
+        v[u] = e < (n - 1) * mm ? B[lv.E + e] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int e = base + u * BCR_THREADS + tid;
+        if (e < (n - 1) * mm) {
+          const int i = e / mm, w = e - i * mm, r = w / m, c = w - r * m;
+          T[((i + 1) * m + c) * ld + i * m + r] = v[u];
+        }
+      }
+    }
+    double vl[BCR_EPT];
+#pragma unroll
+    for (int u = 0; u < BCR_EPT; ++u) {
+      const int w = tid + u * BCR_THREADS;
+      vl[u] = w < mm ? B[lv.E + (long)(n - 1) * mm + w] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < BCR_EPT; ++u) {
+      const int w = tid + u * BCR_THREADS;
+      if (w < mm) { const int r = w / m, c = w - r * m; T[((n - 1) * m + r) * ld + c] += vl[u]; }
+    }
+  }
+  __syncthreads();
+  bool bad = false;
+  for (int j = 0; j < nb; ++j) {
+    const int c0 = 6 * j;
+    double Li[36];
+    if (!chol6_inverse_ld(T + c0 * ld + c0, ld, Li)) bad = true;
+    double li_mine = 0.0;  // Li[tid] by a static select: a dynamic index would put Li in scratch memory
+#pragma unroll
+    for (int e = 0; e < 36; ++e) li_mine = (e == tid) ? Li[e] : li_mine;
+    if (tid < 36) sLi[j * 36 + tid] = li_mine;
+    for (int rho = c0 + 6 + tid; rho < R; rho += BCR_THREADS) {
+      double* row = T + rho * ld + c0;
+      double x[6], o[6];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) x[t] = row[t];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t <= c; ++t) s += x[t] * Li[6 * c + t];
+        o[c] = s;
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) row[c] = o[c];
+    }
+    __syncthreads();
+    const int nbc = nb - 1 - j, rows = R - (c0 + 6);
+    for (int w = tid; w < rows * nbc; w += BCR_THREADS) {
+      const int rr = w / nbc, rho = c0 + 6 + rr, kb = j + 1 + (w - rr * nbc), cb = 6 * kb;
+      if (rho < cb) continue;  // lower triangle (the right-hand-side row is below everything)
+      const double* a = T + rho * ld + c0;
+      double x[6];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) x[t] = a[t];
+      double* out = T + rho * ld + cb;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const double* b = T + (cb + c) * ld + c0;
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) s += x[t] * b[t];
+        out[c] -= s;
+      }
+    }
+    __syncthreads();
+  }
+  // backward sweep on y (row Nd of T)
+  double* y = T + (long)Nd * ld;
+  for (int j = nb - 1; j >= 0; --j) {
+    const int c0 = 6 * j;
+    if (tid < 6) {  // x_j = L_jj^-T y_j:  x[c] = sum_{t >= c} Li[t][c] y[t]
+      double x = 0.0;
+#pragma unroll
+      for (int t = 0; t < 6; ++t) x += (t >= tid) ? sLi[j * 36 + 6 * t + tid] * y[c0 + t] : 0.0;
+      xs[c0 + tid] = x;
+    }
+    __syncthreads();
+    for (int rho = tid; rho < c0; rho += BCR_THREADS) {  // y_rho -= sum_c L[c0 + c][rho] x_j[c]
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) s += T[(c0 + c) * ld + rho] * xs[c0 + c];
+      y[rho] -= s;
+    }
+    __syncthreads();
+  }
+  double* __restrict__ X = B + plan.X;
+  for (int e = tid; e < Nd; e += BCR_THREADS) {
+    const int i = e / m, c = e - i * m;
+    const long o = (long)i << level;
+    X[o * m + c] = xs[e];
+    if (c < 6 * cnt[o]) dc[6L * cam0[o] + c] = xs[e];
+  }
+  if (bad && tid == 0) atomic_add_f64(badv, 1.0);
 }

@@ -141,7 +141,7 @@ struct ba_handle {
   BcrPlan bcr_plan{};
   double* bcr_B = nullptr;
   size_t bcr_zero = 0;  // doubles of the level-0 arrays (cleared before every assembly)
-  size_t bcr_lds_factor = 0, bcr_lds_update = 0;
+  size_t bcr_lds_factor = 0, bcr_lds_update = 0, bcr_lds_tail = 0;
   const long *bcr_dst = nullptr, *bcr_dst2 = nullptr, *bcr_rdst = nullptr, *bcr_pad = nullptr;
   const unsigned char* bcr_kind = nullptr;
   const int *bcr_cam0 = nullptr, *bcr_cnt = nullptr;
@@ -476,9 +476,10 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
                  h->bcr_dst2, h->bcr_kind, h->bcr_rdst, h->bcr_pad, h->bcr_npad, lam, o.min_diag, mode);
     for (int l = 0; l < pl.n_levels; ++l) {
       launch_timed_lds(h, KT_PCG, k_bcr_factor, pl.lv[l].n_elim, BCR_THREADS, h->bcr_lds_factor, B, pl, l, ctrl, d.scal + SC_BADV);
-      if (l + 1 < pl.n_levels)
-        launch_timed_lds(h, KT_PCG, k_bcr_update, pl.lv[l + 1].n, BCR_THREADS, h->bcr_lds_update, B, pl, l, ctrl);
+      launch_timed_lds(h, KT_PCG, k_bcr_update, pl.lv[l + 1].n, BCR_THREADS, h->bcr_lds_update, B, pl, l, ctrl);
     }
+    launch_timed_lds(h, KT_PCG, k_bcr_tail, 1, BCR_THREADS, h->bcr_lds_tail, B, pl, h->bcr_cam0, h->bcr_cnt, ctrl, d.dc,
+                     d.scal + SC_BADV);
     for (int l = pl.n_levels - 1; l >= 0; --l)
       launch_timed(h, KT_PCG, k_bcr_backsolve, pl.lv[l].n_elim, BCR_THREADS, B, pl, l, h->bcr_cam0, h->bcr_cnt, ctrl, d.dc);
     *pcg_iters = -1;
@@ -1490,19 +1491,20 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
         long off = 0;
         int n_l = N, nl = 0;
         // level-0 arrays first and contiguous: one memset clears them
-        std::vector<int> ns;
-        for (int t = N;; t = (t + 1) / 2) { ns.push_back(t); if (t == 1) break; }
+        std::vector<int> ns;  // block counts: elimination levels while more than the tail's share is left, then the tail
+        const int n_tail = std::max(2, BCR_TAIL_ROWS / m);
+        for (int t = N;; t = (t + 1) / 2) { ns.push_back(t); if (t <= n_tail) break; }
         ok = (int)ns.size() <= BCR_MAX_LEVELS;
         if (ok) {
           for (size_t l = 0; l < ns.size(); ++l) {
             BcrLevel& lv = pl.lv[l];
-            lv.n = ns[l]; lv.n_elim = ns[l] == 1 ? 1 : ns[l] / 2;
+            lv.n = ns[l]; lv.n_elim = l + 1 < ns.size() ? ns[l] / 2 : 0;
             lv.D = off; off += lv.n * mm;
             lv.E = off; off += lv.n * mm;
             lv.r = off; off += (long)lv.n * m;
             if (l == 0) h->bcr_zero = (size_t)off;
           }
-          for (size_t l = 0; l < ns.size(); ++l) {
+          for (size_t l = 0; l + 1 < ns.size(); ++l) {
             BcrLevel& lv = pl.lv[l];
             lv.LiT = off; off += lv.n_elim * mm;
             lv.Fa = off; off += lv.n_elim * mm;
@@ -1510,7 +1512,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
             lv.y = off; off += (long)lv.n_elim * m;
           }
           pl.X = off; off += (long)N * m;
-          pl.n_levels = (int)ns.size();
+          pl.n_levels = (int)ns.size() - 1;
           (void)n_l; (void)nl;
           // where every upper block of S goes
           h->h_bdst.assign(nu, 0); h->h_bdst2.assign(nu, 0); h->h_bkind.assign(nu, 0); h->h_brdst.assign(Cf, 0);
@@ -1541,6 +1543,11 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
           h->bcr_lds_update = ((size_t)4 * m * (m + 1) + 2 * m) * sizeof(double);
           HIP_TRY(h, hipFuncSetAttribute((const void*)k_bcr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bcr_lds_factor));
           HIP_TRY(h, hipFuncSetAttribute((const void*)k_bcr_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bcr_lds_update));
+          {
+            const size_t nd = (size_t)pl.lv[pl.n_levels].n * m;
+            h->bcr_lds_tail = ((nd + 1) * (nd + 1) + (nd / 6) * 36 + nd) * sizeof(double);
+            HIP_TRY(h, hipFuncSetAttribute((const void*)k_bcr_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bcr_lds_tail));
+          }
           h->banded_solve = false; h->bseg_P = 0; h->dense_solve = false; h->small_solve = false;
         }
       }
