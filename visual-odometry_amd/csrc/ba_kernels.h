@@ -94,7 +94,8 @@ struct DeviceProblem {
   int n_comp;
   const int* lin_lm;     // [n_lin_chunks + 1] first landmark of each k_linearize_flat chunk
   const int* lin_k;      // [n_lin_chunks + 1] first observation of each chunk
-  int n_lin_chunks;      // 0: k_linearize<G> is used
+  int n_lin_chunks;      // 0: no chunk tables (some track is longer than LINF_MAXLM)
+  int lin_flat;          // 1: k_linearize_flat takes the chunks (few cameras); k_backsub_flat takes them whenever they exist
   const int* sch_lm;     // [n_chunks + 1] first landmark of each k_schur_staged chunk
   const int* sch_k;      // [n_chunks + 1] first observation of each chunk (= lm_ptr[sch_lm[.]])
   const unsigned* sch_flush;  // [n_chunks] bit s: the wave writes its accumulators out before step s of the chunk
@@ -106,6 +107,7 @@ struct DeviceProblem {
   int nu, nl, nb;
   // state
   double* W; double* V; double* gp; double* Ugc;
+  double* zmin;          // [L] smallest depth of the landmark over its cameras at the last linearisation (k_backsub's guard)
   // S (upper blocks), rhs and Ugc are consecutive in ONE allocation [nu*36 | 6*Cf | 27*C]: the buffer
   // that the multi-GPU all-reduce sums (ba_solver.hip).  Ugc_part is this GPU's partial U / gc.
   double* S; double* rhs; double* Ugc_part; double* Minv;
@@ -200,6 +202,7 @@ __global__ __launch_bounds__(64, ROBUST ? 1 : LIN_WAVES) void k_linearize(Device
     const double P[3] = {P_n[0], P_n[1], P_n[2]};
     prefetch(j + GPW);
     double v[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    double zmn = 1e300;
     for (int k0 = kb; __any(k0 < ke); k0 += G) {
       const int k = k0 + gl;
       const bool act = k < ke;
@@ -213,6 +216,7 @@ __global__ __launch_bounds__(64, ROBUST ? 1 : LIN_WAVES) void k_linearize(Device
         linearize_obs(d.K, poses + 7 * cam, P, first ? u_first : d.o_u[k], first ? v_first : d.o_v[k], r, Jc, Jp, zc);
         nbehind += (zc <= 0.0);
         nzero += (zc == 0.0);
+        zmn = fmin(zmn, zc);
         if (!ROBUST) {
           cost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
         } else {  // robust loss: scale each residual and its Jacobian row
@@ -258,7 +262,9 @@ __global__ __launch_bounds__(64, ROBUST ? 1 : LIN_WAVES) void k_linearize(Device
     for (int i = 0; i < 6; ++i) v[i] = group_sum<G>(v[i]);
 #pragma unroll
     for (int i = 0; i < 3; ++i) g[i] = group_sum<G>(g[i]);
+    zmn = -group_max<G>(-zmn);
     if (gl == 0 && lm_ok) {
+      d.zmin[j] = zmn;
 #pragma unroll
       for (int i = 0; i < 6; ++i) d.V[(long)i * d.L + j] = v[i];
 #pragma unroll
@@ -348,12 +354,13 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_f
   double vg[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) vg[i] = 0.0;
+  double zc = 1e300;
   if (act) {
     const double P[3] = {myP[3 * (lm - jb)], myP[3 * (lm - jb) + 1], myP[3 * (lm - jb) + 2]};
     double pose[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) pose[i] = sPose[7 * cam + i];
-    double r[2], Jc[12], Jp[6], zc;
+    double r[2], Jc[12], Jp[6];
     linearize_obs(d.K, pose, P, u, v, r, Jc, Jp, zc);
     nbehind += (zc <= 0.0);
     nzero += (zc == 0.0);
@@ -402,16 +409,19 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_f
   // V, gp of the chunk's landmarks: rows parked per observation, summed per track in track order
 #pragma unroll
   for (int i = 0; i < 9; ++i) myV[lane * LINF_VSTRIDE + i] = vg[i];
+  myV[lane * LINF_VSTRIDE + 9] = zc;
   __syncthreads();  // myV rows; all U / gc contributions of the workgroup
   if (lm_lane) {
     const int jl = jb + lane;
-    double s9[9];
+    double s9[9], zmn = 1e300;
 #pragma unroll
     for (int i = 0; i < 9; ++i) s9[i] = 0.0;
     for (int t = tb; t < te; ++t) {
 #pragma unroll
       for (int i = 0; i < 9; ++i) s9[i] += myV[t * LINF_VSTRIDE + i];
+      zmn = fmin(zmn, myV[t * LINF_VSTRIDE + 9]);
     }
+    d.zmin[jl] = zmn;
 #pragma unroll
     for (int i = 0; i < 6; ++i) d.V[(long)i * d.L + jl] = s9[i];
 #pragma unroll
@@ -1758,6 +1768,21 @@ __global__ __launch_bounds__(64) void k_solve_components(DeviceProblem d, double
 // ------------------------------------------------------------------------------------------------
 // pose update: trial poses = retract(poses, dc); camera part of the step statistics
 // (g.d, d^T U d, |d|^2, |x|^2).  One thread per camera; runs as the trailing blocks of k_backsub.
+// t <- t + dt, q <- normalise(q (x) [1, dtheta / 2])   (Hamilton product, reference src/geometry.py:504-512).
+// One function for the trial poses that the pose blocks write and for the trial poses that k_backsub_flat forms per
+// observation for the trial cost: the same bits.
+__device__ __forceinline__ void retract_pose(const double* __restrict__ ps, const double dl[6], double po[7]) {
+  po[0] = ps[0] + dl[0]; po[1] = ps[1] + dl[1]; po[2] = ps[2] + dl[2];
+  const double w1 = ps[3], x1 = ps[4], y1 = ps[5], z1 = ps[6];
+  const double x2 = 0.5 * dl[3], y2 = 0.5 * dl[4], z2 = 0.5 * dl[5];
+  const double w = w1 - x1 * x2 - y1 * y2 - z1 * z2;
+  const double x = w1 * x2 + x1 + y1 * z2 - z1 * y2;
+  const double y = w1 * y2 - x1 * z2 + y1 + z1 * x2;
+  const double z = w1 * z2 + x1 * y2 - y1 * x2 + z1;
+  const double inv = 1.0 / sqrt(w * w + x * x + y * y + z * z);
+  po[3] = w * inv; po[4] = x * inv; po[5] = y * inv; po[6] = z * inv;
+}
+
 __device__ __forceinline__ void pose_update_block(const DeviceProblem& d, const double* __restrict__ poses,
                                                   double* __restrict__ poses_t, int cam_block, double* red /*[4]*/) {
   const int cam = cam_block * 256 + threadIdx.x;
@@ -1782,16 +1807,10 @@ __device__ __forceinline__ void pose_update_block(const DeviceProblem& d, const 
 #pragma unroll
         for (int c = 0; c < 6; ++c) dhd += dl[i] * u[i <= c ? sym6_index(i, c) : sym6_index(c, i)] * dl[c];
       }
-      pt[0] = ps[0] + dl[0]; pt[1] = ps[1] + dl[1]; pt[2] = ps[2] + dl[2];
-      // q <- normalise(q (x) [1, dtheta / 2])   (Hamilton product, reference src/geometry.py:504-512)
-      const double w1 = ps[3], x1 = ps[4], y1 = ps[5], z1 = ps[6];
-      const double x2 = 0.5 * dl[3], y2 = 0.5 * dl[4], z2 = 0.5 * dl[5];
-      double w = w1 - x1 * x2 - y1 * y2 - z1 * z2;
-      double x = w1 * x2 + x1 + y1 * z2 - z1 * y2;
-      double y = w1 * y2 - x1 * z2 + y1 + z1 * x2;
-      double z = w1 * z2 + x1 * y2 - y1 * x2 + z1;
-      const double inv = 1.0 / sqrt(w * w + x * x + y * y + z * z);
-      pt[3] = w * inv; pt[4] = x * inv; pt[5] = y * inv; pt[6] = z * inv;
+      double po[7];
+      retract_pose(ps, dl, po);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) pt[i] = po[i];
       xn = ps[0] * ps[0] + ps[1] * ps[1] + ps[2] * ps[2] + 1.0;
     }
   }
@@ -1920,6 +1939,174 @@ __global__ __launch_bounds__(256) void k_backsub(DeviceProblem d, double lam, do
     atomic_add_f64(&sc[SC_DNORM2], b2);
     atomic_add_f64(&sc[SC_XNORM2], b3);
     if (b4 != 0.0) atomic_add_f64(&sc[SC_NSHORT], b4);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_backsub_flat: k_backsub with ONE LANE PER OBSERVATION (all 64 lanes load W, against 5 of 8 in the group-per-track
+// kernel on tracks of five), plus the trial cost, so that solver iterations need no k_cost launch and no second pass
+// over the observations.  A wave takes one chunk of whole tracks (the chunk tables of k_linearize_flat, built for any
+// camera count): every load is issued in two rounds (W, indices, pixels, V, gp, P, zmin; then the camera steps), the
+// W^T dc rows are parked in LDS and lane l sums the rows of track l in track order, forms dp, applies the cheirality
+// guard and parks the trial point; the observation lanes then retract their camera's pose (retract_pose: the bits that
+// the pose blocks write) and evaluate the trial residual.  The guard's exact test needs the pose of every observing
+// camera; it is skipped whenever |dp| < (1 - GUARD_KEEP) zmin (zmin: the landmark's smallest depth, left by the
+// linearisation), which cannot cross a principal plane: the test then costs 8 B per landmark.
+// Algorithmic bytes: those of k_backsub + k_cost minus the second read of the points: 172 B/obs + 152 B/landmark.
+template <bool ROBUST>
+__global__ __launch_bounds__(256) void k_backsub_flat(DeviceProblem d, double lam, double min_diag,
+                                                      const double* __restrict__ pts, double* __restrict__ pts_t,
+                                                      const double* __restrict__ poses, double* __restrict__ poses_t,
+                                                      int pose_blocks, int guard, int with_cost) {
+  __shared__ double red[4];
+  __shared__ double sT[4][64 * 3];
+  __shared__ double sPt[4][LINF_MAXLM * 3];
+  if (lam < 0.0) {
+    const LmCtrl* c = d.ctrl;
+    if (c->done) return;
+    guard = c->guard_cheirality;
+    lam = c->lam;
+    pts = d.pts_buf[c->sel];
+    pts_t = d.pts_buf[c->sel ^ 1];
+    poses = d.poses_buf[c->sel];
+    poses_t = d.poses_buf[c->sel ^ 1];
+  }
+  if ((int)blockIdx.x >= (int)gridDim.x - pose_blocks) {
+    pose_update_block(d, poses, poses_t, blockIdx.x - (gridDim.x - pose_blocks), red);
+    return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  const bool have = c < d.n_lin_chunks;
+  int kb = 0, ke = 0, jb = 0, je = 0;
+  if (have) { jb = d.lin_lm[c]; je = d.lin_lm[c + 1]; kb = d.lin_k[c]; ke = d.lin_k[c + 1]; }
+  const long n = d.n;
+  const int k = kb + lane;
+  const bool act = k < ke;
+  // round 1: everything whose address is known from the chunk bounds
+  int f = -1, cam = 0, lm = jb;
+  double w[18], u = 0.0, v = 0.0;
+#pragma unroll
+  for (int i = 0; i < 18; ++i) w[i] = 0.0;
+  if (act) {
+    f = d.o_free[k];
+    lm = d.o_lm[k];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) w[i] = d.W[(long)i * n + k];
+    if (with_cost) { cam = d.o_cam[k]; u = d.o_u[k]; v = d.o_v[k]; }
+  }
+  const bool lm_lane = lane < je - jb;
+  const long j = jb + lane;
+  int tb = 0, te = 0;
+  double V6[6] = {1, 0, 0, 1, 0, 1}, g[3] = {0, 0, 0}, P[3] = {0, 0, 0}, zmn = 0.0;
+  if (lm_lane) {
+    tb = d.lm_ptr[j] - kb; te = d.lm_ptr[j + 1] - kb;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) V6[i] = d.V[(long)i * d.L + j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g[i] = d.gp[(long)i * d.L + j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) P[i] = pts[3 * j + i];
+    if (guard) zmn = d.zmin[j];
+  }
+  // round 2: the camera step of this observation (and, for the trial cost, its pose)
+  double dl[6] = {0, 0, 0, 0, 0, 0}, ps[7] = {0, 0, 0, 1, 0, 0, 0};
+  if (act && f >= 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dl[i] = d.dc[6 * f + i];
+  }
+  if (act && with_cost) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) ps[i] = poses[7 * cam + i];
+  }
+  double* myT = sT[wave];
+  double* myP = sPt[wave];
+#pragma unroll
+  for (int cc = 0; cc < 3; ++cc) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) t += w[3 * i + cc] * dl[i];
+    myT[3 * lane + cc] = t;
+  }
+  __syncthreads();  // (each wave only reads its own rows; every wave of the block reaches the barriers)
+  double gd = 0.0, dhd = 0.0, dn = 0.0, xn = 0.0;
+  int nshort = 0;
+  if (lm_lane) {
+    double t[3] = {0, 0, 0};
+    for (int r = tb; r < te; ++r) {
+      t[0] += myT[3 * r]; t[1] += myT[3 * r + 1]; t[2] += myT[3 * r + 2];
+    }
+    double vi[6], s3[3], dp[3];
+    damped_inv3(V6, lam, min_diag, vi);
+    s3[0] = g[0] + t[0]; s3[1] = g[1] + t[1]; s3[2] = g[2] + t[2];
+    sym3_mul(vi, s3, dp);
+    dp[0] = -dp[0]; dp[1] = -dp[1]; dp[2] = -dp[2];
+    if (guard) {
+      const double keep = (1.0 - GUARD_KEEP) * zmn;
+      if (!(zmn > 0.0) || dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2] >= keep * keep) {  // rare: the exact test of k_backsub
+        double alpha = 1.0;
+        for (int r = tb; r < te; ++r) {
+          const double* pc = poses + 7 * d.o_cam[kb + r];
+          const double qw = pc[3], qx = pc[4], qy = pc[5], qz = pc[6];
+          const double r3[3] = {2 * qx * qz + 2 * qw * qy, 2 * qy * qz - 2 * qw * qx, 1 - 2 * qx * qx - 2 * qy * qy};
+          const double z0 = (P[0] - pc[0]) * r3[0] + (P[1] - pc[1]) * r3[1] + (P[2] - pc[2]) * r3[2];
+          const double dz = dp[0] * r3[0] + dp[1] * r3[1] + dp[2] * r3[2];
+          if (z0 > 0.0 && z0 + dz < GUARD_KEEP * z0) alpha = fmin(alpha, (1.0 - GUARD_KEEP) * z0 / -dz);
+        }
+        if (alpha < 1.0) { dp[0] *= alpha; dp[1] *= alpha; dp[2] *= alpha; nshort = 1; }
+      }
+    }
+    const double Pt[3] = {P[0] + dp[0], P[1] + dp[1], P[2] + dp[2]};
+    pts_t[3 * j] = Pt[0]; pts_t[3 * j + 1] = Pt[1]; pts_t[3 * j + 2] = Pt[2];
+    myP[3 * lane] = Pt[0]; myP[3 * lane + 1] = Pt[1]; myP[3 * lane + 2] = Pt[2];
+    gd = g[0] * dp[0] + g[1] * dp[1] + g[2] * dp[2];
+    const double vdp0 = V6[0] * dp[0] + V6[1] * dp[1] + V6[2] * dp[2];
+    const double vdp1 = V6[1] * dp[0] + V6[3] * dp[1] + V6[4] * dp[2];
+    const double vdp2 = V6[2] * dp[0] + V6[4] * dp[1] + V6[5] * dp[2];
+    dhd = dp[0] * vdp0 + dp[1] * vdp1 + dp[2] * vdp2 + 2.0 * (t[0] * dp[0] + t[1] * dp[1] + t[2] * dp[2]);
+    dn = dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];
+    xn = P[0] * P[0] + P[1] * P[1] + P[2] * P[2];
+  }
+  double cost = 0.0;
+  int nbehind = 0, nzero = 0;
+  if (with_cost) {
+    __syncthreads();
+    if (act) {
+      const int li = lm - jb;
+      const double Pt[3] = {myP[3 * li], myP[3 * li + 1], myP[3 * li + 2]};
+      double po[7];
+      if (f >= 0) retract_pose(ps, dl, po);
+      else {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) po[i] = ps[i];
+      }
+      double R[9], X[3], r0, r1;
+      quat_to_R(po + 3, R);
+      to_camera(R, po, Pt, X);
+      reproject(d.K, X, u, v, r0, r1);
+      nbehind = X[2] <= 0.0;
+      nzero = X[2] == 0.0;
+      cost = !ROBUST ? 0.5 * (r0 * r0 + r1 * r1) : robust_cost(d.loss, r0) + robust_cost(d.loss, r1);
+    }
+  }
+  const double b0 = block_sum_256(gd, red), b1 = block_sum_256(dhd, red), b2 = block_sum_256(dn, red),
+               b3 = block_sum_256(xn, red), b4 = block_sum_256((double)nshort, red);
+  double b5 = 0.0, b6 = 0.0, b7 = 0.0;
+  if (with_cost) {
+    b5 = block_sum_256(cost, red); b6 = block_sum_256((double)nbehind, red); b7 = block_sum_256((double)nzero, red);
+  }
+  if (threadIdx.x == 0) {
+    double* sc = SCAL_MINE(d);
+    atomic_add_f64(&sc[SC_GDOT], b0);
+    atomic_add_f64(&sc[SC_DHD], b1);
+    atomic_add_f64(&sc[SC_DNORM2], b2);
+    atomic_add_f64(&sc[SC_XNORM2], b3);
+    if (b4 != 0.0) atomic_add_f64(&sc[SC_NSHORT], b4);
+    if (with_cost) {
+      atomic_add_f64(&sc[SC_COST_T], b5);
+      if (b6 != 0.0) atomic_add_f64(&sc[SC_NBEHIND_T], b6);
+      if (b7 != 0.0) atomic_add_f64(&sc[SC_ZEROZ], b7);
+    }
   }
 }
 

@@ -115,6 +115,8 @@ struct ba_handle {
   std::vector<uint8_t> fixed;
   int g_lin = 16, g_schur = 64, lpg_lin = 1, lpg_schur = 1, lpg_back = 1;
   long contrib_rows = 0;  // rows of the contribution tiles that k_schur_staged writes per launch
+  bool use_flat_backsub = true;  // BA_BACKSUB_FLAT=0: the group-per-track kernel + k_cost
+  int flat_chunks = 0;  // chunks of whole tracks (<= 64 observations) for the lane-per-observation kernels; 0: none
   int lin_cpw = 0;  // 1: k_linearize_flat (one chunk of whole tracks per wave) replaces k_linearize<G>
   int schur_cpb = 0;  // > 0: k_schur_staged with this many chunks per block
   bool small_solve = false;
@@ -380,9 +382,19 @@ void launch_linearize(ba_handle* h, const double* poses, const double* pts) {
   }
 }
 
-// lam < 0: solver mode
-void launch_backsub(ba_handle* h, double lam, const double* pts, double* pts_t, const double* poses, double* poses_t) {
+// lam < 0: solver mode.  Returns true if the trial cost was computed by the same launch (k_backsub_flat in solver mode).
+bool launch_backsub(ba_handle* h, double lam, const double* pts, double* pts_t, const double* poses, double* poses_t) {
   const DeviceProblem& d = h->d;
+  if (h->flat_chunks > 0 && h->use_flat_backsub) {
+    const int pb = grid_for(d.C);
+    const int grid = grid_for(h->flat_chunks, 4) + pb;
+    const int with_cost = lam < 0.0;
+    if (d.loss.kind == LOSS_LINEAR)
+      launch_timed(h, KT_BACKSUB, k_backsub_flat<false>, grid, 256, d, lam, h->opt.min_diag, pts, pts_t, poses, poses_t, pb, 0, with_cost);
+    else
+      launch_timed(h, KT_BACKSUB, k_backsub_flat<true>, grid, 256, d, lam, h->opt.min_diag, pts, pts_t, poses, poses_t, pb, 0, with_cost);
+    return with_cost != 0;
+  }
   const int G = h->g_lin, lpg = h->lpg_back;
   const long groups = (d.L_obs + lpg - 1) / lpg;
   const int pb = grid_for(d.C);  // trailing blocks: pose retraction + camera step statistics
@@ -395,6 +407,7 @@ void launch_backsub(ba_handle* h, double lam, const double* pts, double* pts_t, 
     case 32: launch_timed(h, KT_BACKSUB, k_backsub<32>, grid, 256, d, lam, md, pts, pts_t, lpg, poses, poses_t, pb, guard); break;
     default: launch_timed(h, KT_BACKSUB, k_backsub<64>, grid, 256, d, lam, md, pts, pts_t, lpg, poses, poses_t, pb, guard); break;
   }
+  return false;
 }
 
 void launch_schur(ba_handle* h, double lam) {
@@ -577,8 +590,8 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
 
 // step statistics + trial state + trial cost (all arguments null / negative: solver mode)
 void enqueue_trial(ba_handle* h, double lam, const double* poses, const double* pts, double* poses_t, double* pts_t) {
-  launch_backsub(h, lam, pts, pts_t, poses, poses_t);
-  launch_cost(h, poses_t, pts_t, SC_COST_T, SC_NBEHIND_T, nullptr);
+  if (!launch_backsub(h, lam, pts, pts_t, poses, poses_t))
+    launch_cost(h, poses_t, pts_t, SC_COST_T, SC_NBEHIND_T, nullptr);
 }
 
 int fetch_scalars(ba_handle* h) {
@@ -883,7 +896,8 @@ int ba_problem_info(const ba_handle* h, int64_t* info) {
                                     h->bcr_solve ? h->bcr_plan.m / 6 : h->banded_solve ? h->bshape.bw : 0,
                                     h->bcr_solve ? h->bcr_plan.n_levels : h->banded_solve ? h->bshape.na : 0,
                                     h->bcr_solve ? h->bcr_plan.N : h->bseg_P,
-                                    h->Cf, h->L_obs, h->lin_cpw > 0 ? 1 : 0, h->d.n_comp};
+                                    h->Cf, h->L_obs, (h->lin_cpw > 0 ? 1 : 0) | (h->flat_chunks > 0 && h->use_flat_backsub ? 2 : 0),
+                                    h->d.n_comp};
   for (int i = 0; i < BA_INFO_COUNT; ++i) info[i] = v[i];
   return BA_OK;
 }
@@ -1137,10 +1151,12 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
   // ---- k_linearize_flat chunks: whole tracks, <= 64 observations and <= LINF_MAXLM landmarks each
   std::vector<int> lin_lm(1, 0), lin_k(1, 0);
   h->lin_cpw = 0;
+  h->flat_chunks = 0;
+  h->use_flat_backsub = env_int("BA_BACKSUB_FLAT", 1) != 0;
   {
     int maxlen = 0;
     for (int j = 0; j < L_obs; ++j) maxlen = std::max(maxlen, lm_ptr[j + 1] - lm_ptr[j]);
-    if (env_int("BA_LIN_FLAT", 1) != 0 && C <= LINF_MAXC && maxlen <= LINF_MAXLM && L_obs > 0) {
+    if (maxlen <= LINF_MAXLM && L_obs > 0) {
       lin_lm.clear(); lin_k.clear();
       for (int j = 0; j < L_obs;) {
         lin_lm.push_back(j);
@@ -1151,7 +1167,8 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
       }
       lin_lm.push_back(L_obs);
       lin_k.push_back(lm_ptr[L_obs]);
-      h->lin_cpw = 1;
+      h->flat_chunks = (int)lin_lm.size() - 1;
+      if (env_int("BA_LIN_FLAT", 1) != 0 && C <= LINF_MAXC) h->lin_cpw = 1;
     }
   }
   // ---- k_schur_staged tables: chunks (consecutive landmarks, <= SCH_CAP observations, <= SCH_MAXLM
@@ -1581,7 +1598,8 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
                    (intr[4] != 0.0 || intr[5] != 0.0 || intr[6] != 0.0) ? 1 : 0};
   d.loss = RobustLoss{h->opt.loss, h->opt.f_scale * h->opt.f_scale, 1.0 / (h->opt.f_scale * h->opt.f_scale)};
   d.nu = nu; d.nl = nl; d.nb = nb;
-  d.n_lin_chunks = h->lin_cpw > 0 ? (int)lin_lm.size() - 1 : 0;
+  d.n_lin_chunks = h->flat_chunks;
+  d.lin_flat = h->lin_cpw > 0 ? 1 : 0;
   if (h->lin_cpw > 0) {
     const int lds = (int)linf_lds_bytes(C);
     HIP_TRY(h, hipFuncSetAttribute((const void*)k_linearize_flat<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -1609,7 +1627,8 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
       (rc = dev_alloc(h, &d.contrib, (size_t)contrib_rows * CTR_ROW)))
     return rc;
   if ((rc = dev_alloc(h, &d.W, (size_t)18 * n)) || (rc = dev_alloc(h, &d.V, (size_t)6 * L)) ||
-      (rc = dev_alloc(h, &d.gp, (size_t)3 * L)) || (rc = dev_alloc(h, &d.Ugc_part, (size_t)27 * C)) ||
+      (rc = dev_alloc(h, &d.gp, (size_t)3 * L)) || (rc = dev_alloc(h, &d.zmin, (size_t)L)) ||
+      (rc = dev_alloc(h, &d.Ugc_part, (size_t)27 * C)) ||
       (rc = dev_alloc(h, &d.S, (size_t)36 * (nu + gap_blocks + nl))) ||
       (rc = dev_alloc(h, &h->scal_fold, (size_t)SC_COUNT + FOLD_MAX_RANKS)) ||
       (rc = dev_alloc(h, &d.Ugc_slab, (size_t)nslab_u * 27 * C + (size_t)SC_COUNT * SCAL_SLABS +
