@@ -102,52 +102,10 @@ __device__ __forceinline__ bool chol6_inverse_ld(const double* A, int ld, double
 
 constexpr int BCR_EPT = (BCR_MAX_M * BCR_MAX_M + BCR_THREADS - 1) / BCR_THREADS;  // entries of a block per thread
 
-// ------------------------------------------------------------------------------------------------
-// k_bcr_factor: one workgroup per eliminated block i of a level.  The tall matrix
-//     T = [ D_i ; E_{i-1} ; E_i^T ; I ; r_i^T ]        ((4 m + 1) x m, in LDS)
-// goes through a right-looking block Cholesky of its top m x m part, 6 columns at a time (every thread factors the
-// 6x6 diagonal block itself, as k_banded_factor does; a thread then scales one row of the panel; in the trailing
-// update a thread takes one row and one 6-wide column block: 6 panel entries and a 6x6 block of L out of LDS for 36
-// multiply-adds): what is left below D_i is Fa = E_{i-1} L^-T, Fb = E_i^T L^-T, L^-T and y^T = (L^-1 r_i)^T.
-// All global loads are issued before the first use (one round trip, not one per loop iteration).
-// (Levels have n >= 3 blocks: smaller systems go to k_bcr_tail.)
-__global__ __launch_bounds__(BCR_THREADS) void k_bcr_factor(double* __restrict__ B, BcrPlan plan, int level, const LmCtrl* ctrl,
-                                                            double* __restrict__ badv) {
-  extern __shared__ double lds[];
-  if (ctrl && ctrl->done) return;
-  const BcrLevel lv = plan.lv[level];
-  const int m = plan.m, ld = m + 1, mm = m * m, nb = m / 6;
-  const int tid = threadIdx.x;
-  const int q = blockIdx.x;                    // q-th eliminated block
-  const int i = 2 * q + 1;                     // its index at this level
-  const int R = 4 * m + 1;
-  double* T = lds;                             // [R][ld]
-  const double* __restrict__ Di = B + lv.D + (long)i * mm;
-  const double* __restrict__ Ea = B + lv.E + (long)(i - 1) * mm;   // block (i - 1, i)
-  const double* __restrict__ Eb = B + lv.E + (long)i * mm;         // block (i, i + 1)
-  {
-    double vd[BCR_EPT], va[BCR_EPT], vb[BCR_EPT];
-#pragma unroll
-    for (int u = 0; u < BCR_EPT; ++u) {
-      const int e = tid + u * BCR_THREADS;
-      vd[u] = va[u] = vb[u] = 0.0;
-      if (e < mm) { vd[u] = Di[e]; va[u] = Ea[e]; vb[u] = Eb[e]; }
-    }
-    const double rv = tid < m ? B[lv.r + (long)i * m + tid] : 0.0;
-#pragma unroll
-    for (int u = 0; u < BCR_EPT; ++u) {
-      const int e = tid + u * BCR_THREADS;
-      if (e < mm) {
-        const int r = e / m, c = e - r * m;
-        T[r * ld + c] = vd[u];
-        T[(3 * m + r) * ld + c] = r == c ? 1.0 : 0.0;
-        T[(m + r) * ld + c] = va[u];          // row r of block i - 1, column c of block i
-        T[(2 * m + c) * ld + r] = vb[u];      // E_i^T: E_i[r][c] is row c of block i + 1, column r of block i
-      }
-    }
-    if (tid < m) T[4 * m * ld + tid] = rv;
-  }
-  __syncthreads();
+// The block Cholesky of the tall matrix T = [D ; Ea ; Eb^T ; I ; r^T] ((4 m + 1) x m in LDS, row stride ld): see
+// k_bcr_factor.  Called by every thread of the workgroup after a barrier that made T visible; returns with a barrier.
+__device__ __forceinline__ bool bcr_factor_T(double* T, int m, int ld, int tid) {
+  const int nb = m / 6, R = 4 * m + 1;
   bool bad = false;
   for (int j = 0; j < nb; ++j) {
     const int c0 = 6 * j;
@@ -196,6 +154,13 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_factor(double* __restrict__
     }
     __syncthreads();
   }
+  return bad;
+}
+
+// Fa, Fb, L^-T, y of eliminated block q of a level, out of the factored T.
+__device__ __forceinline__ void bcr_store_factors(double* __restrict__ B, const BcrLevel& lv, int q, const double* T, int m,
+                                                  int ld, int tid) {
+  const int mm = m * m;
   double* __restrict__ Fa = B + lv.Fa + (long)q * mm;
   double* __restrict__ Fb = B + lv.Fb + (long)q * mm;
   double* __restrict__ LiT = B + lv.LiT + (long)q * mm;
@@ -206,6 +171,57 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_factor(double* __restrict__
     LiT[e] = c >= r ? T[(3 * m + r) * ld + c] : 0.0;
   }
   if (tid < m) B[lv.y + (long)q * m + tid] = T[4 * m * ld + tid];
+}
+
+
+
+// ------------------------------------------------------------------------------------------------
+// k_bcr_factor: one workgroup per eliminated block i of a level.  The tall matrix
+//     T = [ D_i ; E_{i-1} ; E_i^T ; I ; r_i^T ]        ((4 m + 1) x m, in LDS)
+// goes through a right-looking block Cholesky of its top m x m part, 6 columns at a time (every thread factors the
+// 6x6 diagonal block itself, as k_banded_factor does; a thread then scales one row of the panel; in the trailing
+// update a thread takes one row and one 6-wide column block: 6 panel entries and a 6x6 block of L out of LDS for 36
+// multiply-adds): what is left below D_i is Fa = E_{i-1} L^-T, Fb = E_i^T L^-T, L^-T and y^T = (L^-1 r_i)^T.
+// All global loads are issued before the first use (one round trip, not one per loop iteration).
+// (Levels have n >= 3 blocks: smaller systems go to k_bcr_tail.)
+__global__ __launch_bounds__(BCR_THREADS) void k_bcr_factor(double* __restrict__ B, BcrPlan plan, int level, const LmCtrl* ctrl,
+                                                            double* __restrict__ badv) {
+  extern __shared__ double lds[];
+  if (ctrl && ctrl->done) return;
+  const BcrLevel lv = plan.lv[level];
+  const int m = plan.m, ld = m + 1, mm = m * m;
+  const int tid = threadIdx.x;
+  const int q = blockIdx.x;                    // q-th eliminated block
+  const int i = 2 * q + 1;                     // its index at this level
+  double* T = lds;                             // [4 m + 1][ld]
+  const double* __restrict__ Di = B + lv.D + (long)i * mm;
+  const double* __restrict__ Ea = B + lv.E + (long)(i - 1) * mm;   // block (i - 1, i)
+  const double* __restrict__ Eb = B + lv.E + (long)i * mm;         // block (i, i + 1)
+  {
+    double vd[BCR_EPT], va[BCR_EPT], vb[BCR_EPT];
+#pragma unroll
+    for (int u = 0; u < BCR_EPT; ++u) {
+      const int e = tid + u * BCR_THREADS;
+      vd[u] = va[u] = vb[u] = 0.0;
+      if (e < mm) { vd[u] = Di[e]; va[u] = Ea[e]; vb[u] = Eb[e]; }
+    }
+    const double rv = tid < m ? B[lv.r + (long)i * m + tid] : 0.0;
+#pragma unroll
+    for (int u = 0; u < BCR_EPT; ++u) {
+      const int e = tid + u * BCR_THREADS;
+      if (e < mm) {
+        const int r = e / m, c = e - r * m;
+        T[r * ld + c] = vd[u];
+        T[(3 * m + r) * ld + c] = r == c ? 1.0 : 0.0;
+        T[(m + r) * ld + c] = va[u];          // row r of block i - 1, column c of block i
+        T[(2 * m + c) * ld + r] = vb[u];      // E_i^T: E_i[r][c] is row c of block i + 1, column r of block i
+      }
+    }
+    if (tid < m) T[4 * m * ld + tid] = rv;
+  }
+  __syncthreads();
+  const bool bad = bcr_factor_T(T, m, ld, tid);
+  bcr_store_factors(B, lv, q, T, m, ld, tid);
   if (bad && tid == 0) atomic_add_f64(badv, 1.0);
 }
 
@@ -366,6 +382,135 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_backsolve(double* __restric
     X[o * m + tid] = x;
     if (tid < 6 * cnt[o]) dc[6L * cam0[o] + tid] = x;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_bcr_level: k_bcr_update of level l and k_bcr_factor of level l + 1 in ONE launch (one workgroup per block k of level
+// l + 1 = even block e = 2 k of level l).  A block that is even again at level l + 1 only needs its updated D', r' (and
+// E' where it is the last block of an odd count) in memory.  A block that is ODD at level l + 1 is eliminated right
+// here: besides D', r' it forms the two couplings it needs from the factors of ITS OWN odd neighbours at level l,
+//     block (k - 1, k) = -Fa_{e-1} Fb_{e-1}^T,     block (k, k + 1) = -Fa_{e+1} Fb_{e+1}^T   (or E_e where e + 1 does not exist),
+// lays them out as the tall matrix of k_bcr_factor in LDS and factors it: no round trip through memory and one launch
+// per level instead of two.
+__global__ __launch_bounds__(BCR_THREADS) void k_bcr_level(double* __restrict__ B, BcrPlan plan, int level, const LmCtrl* ctrl,
+                                                           double* __restrict__ badv) {
+  extern __shared__ double lds[];
+  if (ctrl && ctrl->done) return;
+  const BcrLevel lv = plan.lv[level], nx = plan.lv[level + 1];
+  const int m = plan.m, ld = m + 1, mm = m * m;
+  const int tid = threadIdx.x;
+  const int k = blockIdx.x, e = 2 * k, n = lv.n;
+  const bool elim = (k & 1) != 0;  // eliminated at level l + 1
+  int ql = -1, qr = -1;
+  if (e >= 1) ql = (e - 1) >> 1; else if ((n & 1) == 0) ql = (n - 1) >> 1;
+  if (e + 1 < n) qr = (e + 1) >> 1;
+  double* FbL = lds;                 // [m][ld] Fb of the left odd block  (rows: block e)
+  double* FaR = FbL + m * ld;        // [m][ld] Fa of the right odd block (rows: block e)
+  double* FbR = FaR + m * ld;        // [m][ld] Fb of the right odd block (rows: block e + 2)
+  double* FaL = FbR + m * ld;        // [m][ld] Fa of the left odd block  (rows: block e - 2)      (elim only)
+  double* yL = FaL + m * ld;         // [m]
+  double* yR = yL + m;               // [m]
+  double* T = yR + m;                // [(4 m + 1)][ld] (elim), or [m][ld] as the staging copy of D'
+  const double* __restrict__ De = B + lv.D + (long)e * mm;
+  const double* __restrict__ Ee = B + lv.E + (long)e * mm;
+  {
+    double v1[BCR_EPT], v2[BCR_EPT], v3[BCR_EPT], v4[BCR_EPT];
+#pragma unroll
+    for (int u = 0; u < BCR_EPT; ++u) {
+      const int w = tid + u * BCR_THREADS;
+      v1[u] = v2[u] = v3[u] = v4[u] = 0.0;
+      if (w < mm) {
+        if (ql >= 0) { v1[u] = B[lv.Fb + (long)ql * mm + w]; if (elim) v4[u] = B[lv.Fa + (long)ql * mm + w]; }
+        if (qr >= 0) { v2[u] = B[lv.Fa + (long)qr * mm + w]; v3[u] = B[lv.Fb + (long)qr * mm + w]; }
+      }
+    }
+    double y1 = 0.0, y2 = 0.0;
+    if (tid < m) {
+      if (ql >= 0) y1 = B[lv.y + (long)ql * m + tid];
+      if (qr >= 0) y2 = B[lv.y + (long)qr * m + tid];
+    }
+#pragma unroll
+    for (int u = 0; u < BCR_EPT; ++u) {
+      const int w = tid + u * BCR_THREADS;
+      if (w < mm) {
+        const int r = w / m, c = w - r * m;
+        FbL[r * ld + c] = v1[u]; FaR[r * ld + c] = v2[u]; FbR[r * ld + c] = v3[u]; FaL[r * ld + c] = v4[u];
+      }
+    }
+    if (tid < m) { yL[tid] = y1; yR[tid] = y2; }
+  }
+  __syncthreads();
+  double* __restrict__ Dn = B + nx.D + (long)k * mm;
+  double* __restrict__ En = B + nx.E + (long)k * mm;
+  const bool copy_E = qr < 0;                            // n odd, e = n - 1: blocks n - 1 and 0 stay coupled directly
+  const bool need_E = !elim && k == nx.n - 1;             // an even block's E' is only read where it is the last block of an
+                                                         // odd count (its right neighbour is block 0: the coupling is copied)
+  const int h2 = m / 2;
+  for (int w = tid; w < h2 * h2; w += BCR_THREADS) {
+    const int tr = w / h2, tc = w - tr * h2, r = 2 * tr, c = 2 * tc;
+    const bool lower = tc <= tr;
+    const double *a1 = FbL + r * ld, *a1b = a1 + ld, *a2 = FaR + r * ld, *a2b = a2 + ld;
+    const double *b1 = FbL + c * ld, *b1b = b1 + ld, *b2 = FaR + c * ld, *b2b = b2 + ld;
+    if (lower) {
+      double d00 = 0, d01 = 0, d10 = 0, d11 = 0;
+      for (int t = 0; t < m; ++t) {
+        const double x1 = a1[t], x1b = a1b[t], x2 = a2[t], x2b = a2b[t];
+        const double p1 = b1[t], p1b = b1b[t], p2 = b2[t], p2b = b2b[t];
+        d00 += x1 * p1 + x2 * p2; d01 += x1 * p1b + x2 * p2b; d10 += x1b * p1 + x2b * p2; d11 += x1b * p1b + x2b * p2b;
+      }
+      const int o00 = r * m + c;
+      T[r * ld + c] = De[o00] - d00; T[r * ld + c + 1] = De[o00 + 1] - d01;
+      T[(r + 1) * ld + c] = De[o00 + m] - d10; T[(r + 1) * ld + c + 1] = De[o00 + m + 1] - d11;
+    }
+    if (elim) {
+      // Ea' = block (k - 1, k):  [r][c] = -sum_t FaL[r][t] FbL[c][t];   Eb'^T: [r][c] = block (k, k + 1)[c][r] = -sum_t FaR[c][t] FbR[r][t]
+      const double *l0 = FaL + r * ld, *l1 = l0 + ld, *g0 = FbR + r * ld, *g1 = g0 + ld;
+      double a00 = 0, a01 = 0, a10 = 0, a11 = 0, t00 = 0, t01 = 0, t10 = 0, t11 = 0;
+      for (int t = 0; t < m; ++t) {
+        const double x0 = l0[t], x1 = l1[t], p0 = b1[t], p1 = b1b[t];
+        a00 += x0 * p0; a01 += x0 * p1; a10 += x1 * p0; a11 += x1 * p1;
+        const double y0 = g0[t], y1 = g1[t], s0 = b2[t], s1 = b2b[t];
+        t00 += y0 * s0; t01 += y0 * s1; t10 += y1 * s0; t11 += y1 * s1;
+      }
+      double* A = T + (m + r) * ld + c;
+      A[0] = -a00; A[1] = -a01; A[ld] = -a10; A[ld + 1] = -a11;
+      double* Tb = T + (2 * m + r) * ld + c;
+      if (copy_E) { t00 = -Ee[c * m + r]; t01 = -Ee[(c + 1) * m + r]; t10 = -Ee[c * m + r + 1]; t11 = -Ee[(c + 1) * m + r + 1]; }
+      Tb[0] = -t00; Tb[1] = -t01; Tb[ld] = -t10; Tb[ld + 1] = -t11;
+      double* I = T + (3 * m + r) * ld + c;
+      I[0] = r == c ? 1.0 : 0.0; I[1] = 0.0; I[ld] = 0.0; I[ld + 1] = r == c ? 1.0 : 0.0;
+    } else if (need_E) {
+      const int o00 = r * m + c;
+      if (copy_E) {
+        En[o00] = Ee[o00]; En[o00 + 1] = Ee[o00 + 1]; En[o00 + m] = Ee[o00 + m]; En[o00 + m + 1] = Ee[o00 + m + 1];
+      } else {  // block (e, e + 2) = -FaR FbR^T
+        const double *b3 = FbR + c * ld, *b3b = b3 + ld;
+        double e00 = 0, e01 = 0, e10 = 0, e11 = 0;
+        for (int t = 0; t < m; ++t) {
+          const double x2 = a2[t], x2b = a2b[t], p3 = b3[t], p3b = b3b[t];
+          e00 += x2 * p3; e01 += x2 * p3b; e10 += x2b * p3; e11 += x2b * p3b;
+        }
+        En[o00] = -e00; En[o00 + 1] = -e01; En[o00 + m] = -e10; En[o00 + m + 1] = -e11;
+      }
+    }
+  }
+  for (int r = tid; r < m; r += BCR_THREADS) {
+    double s = 0.0;
+    for (int t = 0; t < m; ++t) s += FbL[r * ld + t] * yL[t] + FaR[r * ld + t] * yR[t];
+    const double v = B[lv.r + (long)e * m + r] - s;
+    if (elim) T[4 * m * ld + r] = v; else B[nx.r + (long)k * m + r] = v;
+  }
+  __syncthreads();
+  if (!elim) {
+    for (int w = tid; w < mm; w += BCR_THREADS) {  // lower triangle (and the 2 x 2 tiles on the diagonal) mirrored
+      const int r = w / m, c = w - r * m;
+      Dn[w] = (c <= r || (c == r + 1 && (r & 1) == 0)) ? T[r * ld + c] : T[c * ld + r];
+    }
+    return;
+  }
+  const bool bad = bcr_factor_T(T, m, ld, tid);
+  bcr_store_factors(B, nx, k >> 1, T, m, ld, tid);
+  if (bad && tid == 0) atomic_add_f64(badv, 1.0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -143,7 +143,8 @@ struct ba_handle {
   BcrPlan bcr_plan{};
   double* bcr_B = nullptr;
   size_t bcr_zero = 0;  // doubles of the level-0 arrays (cleared before every assembly)
-  size_t bcr_lds_factor = 0, bcr_lds_update = 0, bcr_lds_tail = 0;
+  size_t bcr_lds_factor = 0, bcr_lds_update = 0, bcr_lds_tail = 0, bcr_lds_level = 0;
+  bool bcr_fused = true;  // BA_BCR_FUSED=0: k_bcr_update and k_bcr_factor as separate launches at every level
   const long *bcr_dst = nullptr, *bcr_dst2 = nullptr, *bcr_rdst = nullptr, *bcr_pad = nullptr;
   const unsigned char* bcr_kind = nullptr;
   const int *bcr_cam0 = nullptr, *bcr_cnt = nullptr;
@@ -487,9 +488,18 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
     HIP_TRY(h, hipMemsetAsync(B, 0, h->bcr_zero * sizeof(double), h->stream));
     launch_timed(h, KT_PCG, k_bcr_assemble, grid_for((long)d.nu * 36 + 6L * d.Cf + h->bcr_npad), 256, d, B, pl.m, h->bcr_dst,
                  h->bcr_dst2, h->bcr_kind, h->bcr_rdst, h->bcr_pad, h->bcr_npad, lam, o.min_diag, mode);
-    for (int l = 0; l < pl.n_levels; ++l) {
-      launch_timed_lds(h, KT_PCG, k_bcr_factor, pl.lv[l].n_elim, BCR_THREADS, h->bcr_lds_factor, B, pl, l, ctrl, d.scal + SC_BADV);
-      launch_timed_lds(h, KT_PCG, k_bcr_update, pl.lv[l + 1].n, BCR_THREADS, h->bcr_lds_update, B, pl, l, ctrl);
+    if (h->bcr_fused && pl.n_levels > 0) {
+      // factor of level 0; then one launch per level: the update of level l with the factor of level l + 1; the last
+      // update leaves the tail system
+      launch_timed_lds(h, KT_PCG, k_bcr_factor, pl.lv[0].n_elim, BCR_THREADS, h->bcr_lds_factor, B, pl, 0, ctrl, d.scal + SC_BADV);
+      for (int l = 0; l + 1 < pl.n_levels; ++l)
+        launch_timed_lds(h, KT_PCG, k_bcr_level, pl.lv[l + 1].n, BCR_THREADS, h->bcr_lds_level, B, pl, l, ctrl, d.scal + SC_BADV);
+      launch_timed_lds(h, KT_PCG, k_bcr_update, pl.lv[pl.n_levels].n, BCR_THREADS, h->bcr_lds_update, B, pl, pl.n_levels - 1, ctrl);
+    } else {
+      for (int l = 0; l < pl.n_levels; ++l) {
+        launch_timed_lds(h, KT_PCG, k_bcr_factor, pl.lv[l].n_elim, BCR_THREADS, h->bcr_lds_factor, B, pl, l, ctrl, d.scal + SC_BADV);
+        launch_timed_lds(h, KT_PCG, k_bcr_update, pl.lv[l + 1].n, BCR_THREADS, h->bcr_lds_update, B, pl, l, ctrl);
+      }
     }
     launch_timed_lds(h, KT_PCG, k_bcr_tail, 1, BCR_THREADS, h->bcr_lds_tail, B, pl, h->bcr_cam0, h->bcr_cnt, ctrl, d.dc,
                      d.scal + SC_BADV);
@@ -1560,6 +1570,10 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
           h->bcr_lds_update = ((size_t)4 * m * (m + 1) + 2 * m) * sizeof(double);
           HIP_TRY(h, hipFuncSetAttribute((const void*)k_bcr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bcr_lds_factor));
           HIP_TRY(h, hipFuncSetAttribute((const void*)k_bcr_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bcr_lds_update));
+          h->bcr_lds_level = ((size_t)(4 * m + 4 * m + 1) * (m + 1) + 2 * m) * sizeof(double);
+          h->bcr_fused = env_int("BA_BCR_FUSED", 1) != 0 && h->bcr_lds_level <= 160 * 1024;
+          if (h->bcr_fused)
+            HIP_TRY(h, hipFuncSetAttribute((const void*)k_bcr_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bcr_lds_level));
           {
             const size_t nd = (size_t)pl.lv[pl.n_levels].n * m;
             h->bcr_lds_tail = ((nd + 1) * (nd + 1) + (nd / 6) * 36 + nd) * sizeof(double);
