@@ -46,6 +46,8 @@ def algorithmic_bytes(kernel: str, nobs: int, n_lm: int, n_cam: int, info: dict)
     if kernel == "k_schur":  # read W + cam idx; per landmark V + gp; S written once
         return 148.0 * nobs + 96.0 * n_lm
     if kernel == "k_backsub":  # read W + cam idx; per landmark V, gp, P read, P written
+        if info.get("linearize_flat", 0) & 2:  # k_backsub_flat: + pixels, camera index and pose id for the trial cost, zmin
+            return 172.0 * nobs + 152.0 * n_lm
         return 148.0 * nobs + 144.0 * n_lm
     if kernel == "k_cost":
         return 24.0 * nobs + 24.0 * n_lm

@@ -1496,6 +1496,7 @@ constexpr int SMALL_ROWS_PER_WAVE = 60;  // 10 cameras per wave
 constexpr int SMALL_MAX_ROWS = SMALL_VPT * (SMALL_THREADS / 64) * SMALL_ROWS_PER_WAVE;  // 960 = 160 free cameras
 constexpr int SMALL_MAX_NB = 2;          // upper blocks per thread: nu <= 1024
 constexpr int SMALL_GREG = 20;           // gather offsets a row thread keeps in registers
+constexpr int SMALL_ZSTRIDE = 7;         // doubles per camera of z and r in LDS: 6 | pad (a stride of 6 doubles makes the 64-bit reads of 32 lanes share banks two by two)
 constexpr int SMALL_CSTRIDE = 13;        // doubles per SpMV slot: B z_j (6) | B^T z_i (6) | pad (bank spread)
 
 __device__ __forceinline__ void small_load_block(const DeviceProblem& d, int t, double lam, double min_diag,
@@ -1513,16 +1514,18 @@ __device__ __forceinline__ void small_load_block(const DeviceProblem& d, int t, 
 }
 
 // One stored upper block B = S_ij, both directions of the symmetric product into the block's own slot
-__device__ __forceinline__ void small_block_products(const double B[36], int i, int j, const double* z, double* out) {
-  double zj[6], zi[6];
+// Returns the block's share of z^T S z: z_i^T B z_j, twice for an off-diagonal block.
+__device__ __forceinline__ double small_block_products(const double B[36], int i, int j, const double* z, double* out) {
+  double zj[6], zi[6], q = 0.0;
 #pragma unroll
-  for (int c = 0; c < 6; ++c) { zj[c] = z[6 * j + c]; zi[c] = z[6 * i + c]; }
+  for (int c = 0; c < 6; ++c) { zj[c] = z[SMALL_ZSTRIDE * j + c]; zi[c] = z[SMALL_ZSTRIDE * i + c]; }
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
     double a = 0.0;
 #pragma unroll
     for (int c = 0; c < 6; ++c) a += B[6 * r + c] * zj[c];
     out[r] = a;
+    q += zi[r] * a;
   }
   if (i != j) {
 #pragma unroll
@@ -1532,7 +1535,9 @@ __device__ __forceinline__ void small_block_products(const double B[36], int i, 
       for (int r = 0; r < 6; ++r) a += B[6 * r + c] * zi[r];
       out[6 + c] = a;
     }
+    q += q;
   }
+  return q;
 }
 
 template <int NB>
@@ -1544,15 +1549,13 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
     lam = d.ctrl->lam;
   }
   const int N = 6 * d.Cf;
-  double* zv = sm;                  // [N]  z = Minv r: the vector the SpMV multiplies
-  double* rv = zv + N;              // [N]  r, for the wave-local exchange
-  double* Minv = rv + N;            // [Cf][36]
-  double* red = Minv + 36 * d.Cf;   // [8][2]
+  double* zv = sm;                              // [Cf][7]  z = Minv r: the vector the SpMV multiplies (6 | pad)
+  double* rv = zv + SMALL_ZSTRIDE * d.Cf;       // [Cf][7]  r, for the wave-local exchange
+  double* red = rv + SMALL_ZSTRIDE * d.Cf;      // [8][2]
   double* slot = red + 16;          // [nu][SMALL_CSTRIDE]
   int* gl = reinterpret_cast<int*>(slot + (size_t)(d.nu + 1) * SMALL_CSTRIDE);  // [nb] gather list
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
-  for (int t = tid; t < 36 * d.Cf; t += SMALL_THREADS) Minv[t] = d.Minv[t];
   for (int t = tid; t < d.nb; t += SMALL_THREADS) gl[t] = d.sm_gidx[t];
   if (tid < SMALL_CSTRIDE) slot[(size_t)d.nu * SMALL_CSTRIDE + tid] = 0.0;
   double B[NB][36];
@@ -1568,19 +1571,27 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
     }
   }
   // rows of this thread: wave wv (+ 8 per extra entry), lanes 0..59
-  int ent[SMALL_VPT], g0[SMALL_VPT], g1[SMALL_VPT];
+  double mrow[SMALL_VPT][6];  // the preconditioner row of each entry (registers: no LDS copy of Minv)
+  int row6[SMALL_VPT];
+  int ent[SMALL_VPT], g0[SMALL_VPT], g1[SMALL_VPT], zoff[SMALL_VPT];  // zoff: the entry's place in zv / rv
   double x[SMALL_VPT], r[SMALL_VPT], p[SMALL_VPT], sv[SMALL_VPT], z[SMALL_VPT];
 #pragma unroll
   for (int v = 0; v < SMALL_VPT; ++v) {
     const int t = (wv + (SMALL_THREADS / 64) * v) * SMALL_ROWS_PER_WAVE + lane;
     ent[v] = (lane < SMALL_ROWS_PER_WAVE && t < N) ? t : -1;
+    zoff[v] = t + t / 6;
+    row6[v] = t % 6;
     x[v] = 0.0; p[v] = 0.0; sv[v] = 0.0; z[v] = 0.0; r[v] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) mrow[v][c] = 0.0;
     g0[v] = 0; g1[v] = 0;
     if (ent[v] >= 0) {
       r[v] = -d.rhs[t];
-      rv[t] = r[v];
+      rv[zoff[v]] = r[v];
       g0[v] = d.brow_ptr[t / 6];
       g1[v] = d.brow_ptr[t / 6 + 1];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) mrow[v][c] = d.Minv[6 * t + c];  // row (t mod 6) of camera (t / 6)'s 6x6 inverse
     }
   }
   __syncthreads();
@@ -1594,12 +1605,12 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
 #pragma unroll
     for (int v = 0; v < SMALL_VPT; ++v)
       if (ent[v] >= 0) {
-        const int f = ent[v] / 6, i = ent[v] - 6 * f;
+        const double* rc = rv + zoff[v] - row6[v];  // r of this row's camera
         double zi = 0.0;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) zi += Minv[36 * f + 6 * i + c] * rv[6 * f + c];
+        for (int c = 0; c < 6; ++c) zi += mrow[v][c] * rc[c];
         z[v] = zi;
-        zv[ent[v]] = zi;
+        zv[zoff[v]] = zi;
       }
   };
   precondition();
@@ -1608,32 +1619,17 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
   static_assert(SMALL_THREADS == 512, "the partial sums below are written out for 8 waves");
   int it = 0;
   while (true) {
-    // (A) every stored block: B z_j and B^T z_i into its slot
+    // (A) every stored block: B z_j and B^T z_i into its slot, and the block's share of delta = z^T S z; the row
+    // threads add their share of gamma = r.z: both sums are complete at the barrier that publishes the slots (two
+    // barriers per iteration, not three: no reduction after the gather)
+    double pg = 0.0, pd = 0.0;
 #pragma unroll
     for (int k = 0; k < NB; ++k)
       if (ij[k] >= 0)
-        small_block_products(B[k], ij[k] >> 16, ij[k] & 0xffff, zv, slot + (size_t)(tid + k * SMALL_THREADS) * SMALL_CSTRIDE);
-    __syncthreads();
-    // (B) w = S z gathered per row; gamma = r.z, delta = z.w in one reduction
-    double w[SMALL_VPT], pg = 0.0, pd = 0.0;
+        pd += small_block_products(B[k], ij[k] >> 16, ij[k] & 0xffff, zv, slot + (size_t)(tid + k * SMALL_THREADS) * SMALL_CSTRIDE);
 #pragma unroll
-    for (int v = 0; v < SMALL_VPT; ++v) {
-      w[v] = 0.0;
-      if (ent[v] >= 0) {
-        // the first SMALL_GREG slots of the row come from register-held offsets: independent LDS reads
-        double w0 = 0.0, w1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < SMALL_GREG; k += 2) {
-          w0 += slot[gi[v][k]];
-          w1 += slot[gi[v][k + 1]];
-        }
-        const int i = ent[v] % 6;
-        for (int e = g0[v] + SMALL_GREG; e < g1[v]; ++e) w0 += slot[gl[e] + i];
-        w[v] = w0 + w1;
-        pg += r[v] * z[v];
-        pd += w[v] * z[v];
-      }
-    }
+    for (int v = 0; v < SMALL_VPT; ++v)
+      if (ent[v] >= 0) pg += r[v] * z[v];
     pg = wave_sum_dpp(pg);
     pd = wave_sum_dpp(pd);
     if (lane == 0) { red[2 * wv] = pg; red[2 * wv + 1] = pd; }
@@ -1654,7 +1650,23 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
     const double alpha = gamma * fast_rcp(denom);
     inv_gamma_old = fast_rcp(gamma);
     denom_old = denom;
-    // (C) p = z + beta p; s = w + beta s (= S p); x += alpha p; r -= alpha s; z = Minv r
+    // (B) w = S z gathered per row, (C) p = z + beta p; s = w + beta s (= S p); x += alpha p; r -= alpha s; z = Minv r
+    double w[SMALL_VPT];
+#pragma unroll
+    for (int v = 0; v < SMALL_VPT; ++v) {
+      w[v] = 0.0;
+      if (ent[v] >= 0) {
+        // the first SMALL_GREG slots of the row come from register-held offsets: independent LDS reads
+        double w0 = 0.0, w1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < SMALL_GREG; k += 2) {
+          w0 += slot[gi[v][k]];
+          w1 += slot[gi[v][k + 1]];
+        }
+        for (int e = g0[v] + SMALL_GREG; e < g1[v]; ++e) w0 += slot[gl[e] + row6[v]];
+        w[v] = w0 + w1;
+      }
+    }
 #pragma unroll
     for (int v = 0; v < SMALL_VPT; ++v)
       if (ent[v] >= 0) {
@@ -1662,7 +1674,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
         sv[v] = w[v] + beta * sv[v];
         x[v] += alpha * p[v];
         r[v] -= alpha * sv[v];
-        rv[ent[v]] = r[v];
+        rv[zoff[v]] = r[v];
       }
     __builtin_amdgcn_wave_barrier();  // the 6 rows of a camera belong to this wave: LDS keeps a wave's accesses in order
     precondition();

@@ -1294,7 +1294,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
       const int sl = bslot[e];
       sm_gidx[e] = sl < nu ? inv_sm[sl] * SMALL_CSTRIDE : inv_sm[up_of_low[sl - nu - gap_blocks]] * SMALL_CSTRIDE + 6;
     }
-    h->small_lds = ((size_t)2 * 6 * Cf + (size_t)36 * Cf + 16 + (size_t)(nu + 1) * SMALL_CSTRIDE) * sizeof(double) +
+    h->small_lds = ((size_t)2 * SMALL_ZSTRIDE * Cf + 16 + (size_t)(nu + 1) * SMALL_CSTRIDE) * sizeof(double) +
                    (size_t)nb * sizeof(int);
     h->small_solve = env_int("BA_SMALL_SOLVE", 1) && 6 * Cf <= SMALL_MAX_ROWS &&
                      nu <= SMALL_MAX_NB * SMALL_THREADS && h->small_lds <= 160 * 1024;
