@@ -158,6 +158,21 @@ const char* ba_last_error(const ba_handle* h);
 int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int32_t n_obs, const int32_t* obs_cam,
                    const int32_t* obs_pt, const double* obs_uv, const double* intr, const uint8_t* fixed);
 
+/* A quadratic prior on some of the poses of the NEXT ba_set_problem (and of every later one, until replaced; n_prior =
+ * 0 removes it): what a sliding-window driver keeps of the keyframes and landmarks it drops (SURVEY.md section 8 row
+ * f2).  No counterpart in the reference: its keyframe list (visual_odometry.py:13-25,268-277) is never optimised.
+ *   E_prior(x) = c0 + g^T d + 0.5 d^T H d,   d = [d_0 .. d_{n-1}],  d_a = [t_a - tref_a ; 2 vec(qref_a^-1 q_a) / w(qref_a^-1 q_a)]
+ * i.e. d_a are the coordinates of pose cams[a] in the chart of the library's own retraction (t + dt, q (x) [1, dtheta/2])
+ * around ref_poses[a]; H[(6n)^2] row-major, symmetric positive semi-definite; g[6n].  The energy is added to the cost
+ * that ba_solve minimises and reports (ba_evaluate keeps returning the re-projection cost alone); its gradient is exact
+ * and its Hessian the Gauss-Newton one (J = d d_a / d step = I + [a]x + a a^T on the rotation part, a = vec / w).  cams must be distinct, free
+ * cameras of the problem (checked by ba_set_problem); n_prior <= BA_PRIOR_MAX_CAMS.  The camera pairs of the prior
+ * join the block pattern of the reduced camera system.  Not available with ba_comm_init (several ranks) and not in
+ * ba_solve_batched: both return BA_ERR_STATE while a prior is set. */
+#define BA_PRIOR_MAX_CAMS 16
+int ba_set_pose_prior(ba_handle* h, int32_t n_prior, const int32_t* cams, const double* ref_poses, const double* H,
+                      const double* g, double c0);
+
 /* Optimise.  poses[C*7] and points[L*3] are in/out: initial guess in, estimate out (quaternions come
  * back unit-length; fixed poses and unobserved landmarks come back untouched).  Replaces the
  * least_squares call of bundle_adjustment.py:201-219 plus the unpacking of :221-244.

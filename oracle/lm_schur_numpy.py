@@ -270,6 +270,104 @@ def block_jacobi_pcg(S, b, tol, max_iter, C):
     return x, it, r
 
 
+# ----------------------------------------------------------------------------- pose prior (sliding-window marginalisation)
+@dataclass
+class PosePrior:
+    """E = c0 + g^T d + 0.5 d^T H d over the chart coordinates d of `cams` around `ref` (include/ba_amd.h,
+    ba_set_pose_prior): d_a = [t - tref ; 2 vec(qref^-1 q) / w(qref^-1 q)], the inverse of `retract` at ref."""
+    cams: np.ndarray  # (n,)
+    ref: np.ndarray   # (n, 7)
+    H: np.ndarray     # (6n, 6n)
+    g: np.ndarray     # (6n,)
+    c0: float = 0.0
+
+
+def prior_chart(poses, ref):
+    """Chart coordinates d (n,6) of `poses` around `ref` and the Jacobians d d / d step (n,6,6) of the retraction
+    (identity on the translation; I + [a]x + a a^T on the rotation, a = vec / w)."""
+    qc = ref[:, 3:7] * np.array([1.0, -1.0, -1.0, -1.0])
+    qrel = quat_mul(qc, poses[:, 3:7])
+    a = qrel[:, 1:] / qrel[:, :1]
+    d = np.concatenate([poses[:, :3] - ref[:, :3], 2.0 * a], axis=1)
+    J = np.zeros((len(poses), 6, 6))
+    J[:, :3, :3] = np.eye(3)
+    ax = np.zeros((len(poses), 3, 3))
+    ax[:, 0, 1] = -a[:, 2]; ax[:, 0, 2] = a[:, 1]
+    ax[:, 1, 0] = a[:, 2]; ax[:, 1, 2] = -a[:, 0]
+    ax[:, 2, 0] = -a[:, 1]; ax[:, 2, 1] = a[:, 0]
+    J[:, 3:, 3:] = np.eye(3) + ax + a[:, :, None] * a[:, None, :]
+    return d, J
+
+
+def prior_terms(poses, prior: PosePrior):
+    """(energy, gradient (6n,), Gauss-Newton Hessian (6n,6n)) of the prior in the step coordinates at `poses`."""
+    d, J = prior_chart(poses[prior.cams], prior.ref)
+    dv = d.reshape(-1)
+    v = prior.H @ dv + prior.g
+    n = len(prior.cams)
+    Jb = np.zeros((6 * n, 6 * n))
+    for a in range(n):
+        Jb[6 * a:6 * a + 6, 6 * a:6 * a + 6] = J[a]
+    energy = prior.c0 + float(dv @ (0.5 * (v + prior.g)))
+    return energy, Jb.T @ v, Jb.T @ prior.H @ Jb
+
+
+def marginalize(S, b, c, drop_rows):
+    """Schur complement of a quadratic c + b^T x + 0.5 x^T S x over the entries `drop_rows` (minimised out):
+    returns (S', b', c') over the remaining entries, in their order."""
+    n = len(b)
+    drop = np.zeros(n, bool)
+    drop[drop_rows] = True
+    k, r = np.flatnonzero(~drop), np.flatnonzero(drop)
+    Srr = S[np.ix_(r, r)]
+    Skr = S[np.ix_(k, r)]
+    sol = np.linalg.solve(Srr, np.column_stack([Skr.T, b[r]]))
+    return S[np.ix_(k, k)] - Skr @ sol[:, :-1], b[k] - Skr @ sol[:, -1], c - 0.5 * float(b[r] @ sol[:, -1])
+
+
+def window_prior(poses, points, obs_cam, obs_pt, obs_uv, intr, free, drop_cams, prior: Optional["PosePrior"] = None):
+    """What a sliding window keeps of the cameras `drop_cams` it drops: the observations of
+    every landmark that a dropped camera sees (by all cameras of the window) plus the window's own prior, linearised at
+    (poses, points), with those landmarks and the dropped cameras minimised out.  A dropped camera that is fixed is a
+    constant: conditioned on, not eliminated.  Returns (PosePrior over the kept free cameras that the factor touches,
+    in camera order; the landmark rows that went into it) or (None, rows) when nothing couples."""
+    C = len(poses)
+    drop = np.zeros(C, bool)
+    drop[drop_cams] = True
+    lm_drop = np.zeros(len(points), bool)
+    lm_drop[obs_pt[drop[obs_cam]]] = True
+    sel = lm_drop[obs_pt]
+    oc, op, uv = obs_cam[sel], obs_pt[sel], obs_uv[sel]
+    rows = np.flatnonzero(lm_drop)
+    remap = np.full(len(points), -1)
+    remap[rows] = np.arange(len(rows))
+    r, Jc, Jp = linearize(poses, points, oc, op, uv, intr)
+    Jc = Jc * free[oc][:, None, None]
+    U, V, W, gc, gp, cost = normal_blocks(r, Jc, Jp, oc, remap[op], C, len(rows))
+    S, rhs, Vi = schur_system(U, V, W, gc, gp, oc, remap[op], 0.0, free, 0.0)
+    c = cost - 0.5 * float(np.einsum("li,lij,lj->", gp, Vi, gp))
+    fm = np.repeat(free, 6)
+    S[~fm, ~fm] = 0.0  # schur_system's identity rows of the fixed cameras
+    if prior is not None:
+        e, gj, Hj = prior_terms(poses, prior)
+        idx = (6 * prior.cams[:, None] + np.arange(6)[None, :]).reshape(-1)
+        S[np.ix_(idx, idx)] += Hj
+        rhs[idx] += gj
+        c += e
+    touched = np.array([np.any(S[6 * k:6 * k + 6] != 0.0) or np.any(rhs[6 * k:6 * k + 6] != 0.0) for k in range(C)])
+    elim = np.flatnonzero(drop & free & touched)
+    keep = np.flatnonzero(~drop & free & touched)
+    if len(keep) == 0:
+        return None, rows
+    use = np.concatenate([keep, elim])
+    idx = (6 * use[:, None] + np.arange(6)[None, :]).reshape(-1)
+    S2, b2 = S[np.ix_(idx, idx)], rhs[idx]
+    if len(elim):
+        S2, b2, c = marginalize(S2, b2, c, np.arange(6 * len(keep), 6 * len(use)))
+    S2 = 0.5 * (S2 + S2.T)
+    return PosePrior(cams=keep, ref=poses[keep].copy(), H=S2, g=b2, c0=c), rows
+
+
 # ----------------------------------------------------------------------------- LM driver
 @dataclass
 class LMOptions:
@@ -307,7 +405,7 @@ class LMReport:
 
 
 def lm_solve(poses, points, obs_cam, obs_pt, obs_uv, intr, free: Optional[np.ndarray] = None,
-             opt: Optional[LMOptions] = None, uniform_tracks: bool = False):
+             opt: Optional[LMOptions] = None, uniform_tracks: bool = False, prior: Optional[PosePrior] = None):
     """Levenberg-Marquardt with Marquardt diagonal scaling, Schur elimination of the points,
     Nielsen's lambda update.  Mirrors the control flow of csrc/ba_solver.hip::ba_solve."""
     opt = opt or LMOptions()
@@ -323,6 +421,25 @@ def lm_solve(poses, points, obs_cam, obs_pt, obs_uv, intr, free: Optional[np.nda
     Jc = Jc * free[obs_cam][:, None, None]
     r, Jc, Jp, cost = robustify(r, Jc, Jp, opt.loss, opt.f_scale)
     U, V, W, gc, gp, _ = normal_blocks(r, Jc, Jp, obs_cam, obs_pt, C, L)
+    Hoff = None  # the prior's camera-to-camera blocks (its diagonal blocks go into U, its gradient into gc)
+
+    def add_prior(U, gc):
+        n = len(prior.cams)
+        e, gj, Hj = prior_terms(poses, prior)
+        Hoff = np.zeros((6 * C, 6 * C))
+        idx = (6 * prior.cams[:, None] + np.arange(6)[None, :]).reshape(-1)
+        Hoff[np.ix_(idx, idx)] = Hj
+        for a in range(n):
+            ca = prior.cams[a]
+            U[ca] += Hj[6 * a:6 * a + 6, 6 * a:6 * a + 6]
+            gc[ca] += gj[6 * a:6 * a + 6]
+            Hoff[6 * ca:6 * ca + 6, 6 * ca:6 * ca + 6] = 0.0
+        return e, Hoff
+
+    if prior is not None:
+        assert np.all(free[prior.cams]), "the prior's cameras must be free"
+        e, Hoff = add_prior(U, gc)
+        cost += e
     rep.cost0 = cost
     rep.costs.append(cost)
     _, nbehind, _ = linearize(poses, points, obs_cam, obs_pt, obs_uv, intr, want_jac=False)
@@ -338,6 +455,8 @@ def lm_solve(poses, points, obs_cam, obs_pt, obs_uv, intr, free: Optional[np.nda
             S, rhs, Vi = schur_system_sparse(U, V, W, gc, gp, obs_cam, obs_pt, lam, free, opt.min_diag)
         else:
             S, rhs, Vi = schur_system(U, V, W, gc, gp, obs_cam, obs_pt, lam, free, opt.min_diag)
+        if Hoff is not None:
+            S = S + (sp.csr_matrix(Hoff) if sp.issparse(S) else Hoff)
         if opt.linear_solver == "pcg":
             dcv, nit, _ = block_jacobi_pcg(S, -rhs, opt.pcg_tol, opt.pcg_max_iter, C)
             rep.pcg_iters.append(nit)
@@ -355,11 +474,17 @@ def lm_solve(poses, points, obs_cam, obs_pt, obs_uv, intr, free: Optional[np.nda
         Wdp = np.einsum("nij,nj->ni", W, dp[obs_pt])
         dHd = float(np.einsum("ci,cij,cj->", dc, U, dc) + np.einsum("li,lij,lj->", dp, V, dp)
                     + 2.0 * np.sum(dc[obs_cam] * Wdp))
+        if Hoff is not None:
+            dHd += float(dc.reshape(-1) @ Hoff @ dc.reshape(-1))
         pred = -gd - 0.5 * dHd
         poses_t = retract(poses, dc, free)
         points_t = points + dp
         rt, nbehind_t, _ = linearize(poses_t, points_t, obs_cam, obs_pt, obs_uv, intr, want_jac=False)
         cost_t = robustify(rt, None, None, opt.loss, opt.f_scale)[3]
+        if prior is not None:
+            dt_, _ = prior_chart(poses_t[prior.cams], prior.ref)
+            dt_ = dt_.reshape(-1)
+            cost_t += prior.c0 + float(dt_ @ (prior.g + 0.5 * (prior.H @ dt_)))
         rho = (cost - cost_t) / pred if pred > 0 else -1.0
         if opt.guard_cheirality and nbehind_t > nbehind:
             rho = -1.0
@@ -384,6 +509,8 @@ def lm_solve(poses, points, obs_cam, obs_pt, obs_uv, intr, free: Optional[np.nda
             Jc = Jc * free[obs_cam][:, None, None]
             r, Jc, Jp, _ = robustify(r, Jc, Jp, opt.loss, opt.f_scale)
             U, V, W, gc, gp, _ = normal_blocks(r, Jc, Jp, obs_cam, obs_pt, C, L)
+            if prior is not None:
+                _, Hoff = add_prior(U, gc)
         else:
             lam = min(opt.lambda_max, lam * nu)
             nu *= 2.0

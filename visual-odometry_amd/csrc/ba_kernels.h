@@ -63,6 +63,19 @@ struct LmMirror {
   int seq, pad;
 };
 
+// Quadratic pose prior (ba_set_pose_prior; kernels in ba_prior.h)
+constexpr int PRIOR_MAX_CAMS = 16;  // == BA_PRIOR_MAX_CAMS (include/ba_amd.h)
+struct PriorDev {
+  int n;               // cameras under the prior (0: none)
+  double c0;
+  const int* cam;      // [n] camera index
+  const int* fr;       // [n] free-camera index
+  const int* slot;     // [n * n] upper S slot of pair (a, b) when free(a) <= free(b), else -1
+  const double* ref;   // [n][7] chart origins
+  const double* H;     // [6n][6n]
+  const double* g;     // [6n]
+};
+
 struct DeviceProblem {
   int C, Cf, L, L_obs, n;  // cameras, free cameras, landmarks, landmarks with >= 1 observation, observations
   Intrinsics K;
@@ -120,6 +133,7 @@ struct DeviceProblem {
   double* scal;
   LmCtrl* ctrl;
   double* poses_buf[2]; double* pts_buf[2];
+  PriorDev prior;
 };
 
 // ------------------------------------------------------------------------------------------------

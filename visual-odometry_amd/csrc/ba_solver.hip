@@ -6,6 +6,7 @@
 #include "ba_dense.h"
 #include "ba_banded.h"
 #include "ba_bcr.h"
+#include "ba_prior.h"
 
 #include <algorithm>
 #include <chrono>
@@ -116,6 +117,11 @@ struct ba_handle {
   int g_lin = 16, g_schur = 64, lpg_lin = 1, lpg_schur = 1, lpg_back = 1;
   long contrib_rows = 0;  // rows of the contribution tiles that k_schur_staged writes per launch
   bool use_flat_backsub = true;  // BA_BACKSUB_FLAT=0: the group-per-track kernel + k_cost
+  struct PosePrior {             // ba_set_pose_prior: the caller's prior, applied by every ba_set_problem until replaced
+    std::vector<int> cams;
+    std::vector<double> ref, H, g;
+    double c0 = 0.0;
+  } prior;
   int flat_chunks = 0;  // chunks of whole tracks (<= 64 observations) for the lane-per-observation kernels; 0: none
   int lin_cpw = 0;  // 1: k_linearize_flat (one chunk of whole tracks per wave) replaces k_linearize<G>
   int schur_cpb = 0;  // > 0: k_schur_staged with this many chunks per block
@@ -322,6 +328,7 @@ int env_int(const char* name, int dflt) {
 
 constexpr size_t SCAL_BYTES = (size_t)SCAL_SLABS * SC_COUNT * sizeof(double);
 static_assert(LM_HISTORY == BA_HISTORY, "device and ABI history lengths differ");
+static_assert(PRIOR_MAX_CAMS == BA_PRIOR_MAX_CAMS, "device and ABI prior sizes differ");
 
 // read back every copy of the scalar block and fold them into copy 0 (sum; max for the inf-norms)
 int fetch_scalars(ba_handle* h);
@@ -468,13 +475,17 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
   const int mode = lam < 0.0;
   launch_schur(h, lam);
   // the gather also inverts the damped diagonal blocks when they are final there (one GPU, one-workgroup PCG)
-  const int fused_precond = h->schur_cpb > 0 && h->world == 1 && h->small_solve;
+  const int fused_precond = h->schur_cpb > 0 && h->world == 1 && h->small_solve && d.prior.n == 0;
   if (h->schur_cpb > 0)
     launch_timed(h, KT_GATHER, k_gather_S, d.nu + (d.C - d.Cf), 256, d, mode, lam, o.min_diag, fused_precond);
   else launch_timed(h, KT_GATHER, k_reduce_S, grid_for(d.s_slab_stride + 27L * d.C), 256, d, mode);
   const size_t red_count = (size_t)d.nu * 36 + (size_t)6 * d.Cf + (size_t)27 * d.C;
   if (h->world > 1)  // the one exchange step of the path: partial S, reduced rhs, U / gc summed over the shards
     NCCL_TRY(h, h->rccl->AllReduce(d.S, d.S, red_count, ncclDouble, ncclSum, h->comm, h->stream));
+  if (d.prior.n > 0) {  // the pose prior's Gauss-Newton terms, into the assembled system
+    k_prior_add<<<1, 256, 0, h->stream>>>(d, mode ? nullptr : (const double*)d.poses_buf[0]);  // explicit mode: the point that ba_debug_linearization staged
+    note_launch(h);
+  }
   const double tol2 = o.pcg_tol * o.pcg_tol;
   if (h->comp_solve) {
     launch_timed_lds(h, KT_PCG, k_solve_components, d.n_comp, 64, h->comp_lds, d, lam, o.min_diag);
@@ -602,6 +613,10 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
 void enqueue_trial(ba_handle* h, double lam, const double* poses, const double* pts, double* poses_t, double* pts_t) {
   if (!launch_backsub(h, lam, pts, pts_t, poses, poses_t))
     launch_cost(h, poses_t, pts_t, SC_COST_T, SC_NBEHIND_T, nullptr);
+  if (h->d.prior.n > 0) {
+    k_prior_trial<<<1, 128, 0, h->stream>>>(h->d, poses, (const double*)poses_t);
+    note_launch(h);
+  }
 }
 
 int fetch_scalars(ba_handle* h) {
@@ -877,6 +892,7 @@ int ba_comm_init(ba_handle* h, int32_t rank, int32_t world, const char* id128) {
   if (world < 1 || world > FOLD_MAX_RANKS || rank < 0 || rank >= world || !id128)
     return fail(h, BA_ERR_INVALID, "bad rank/world/id (at most %d ranks)", FOLD_MAX_RANKS);
   if (h->comm) return fail(h, BA_ERR_STATE, "communicator already initialised");
+  if (world > 1 && !h->prior.cams.empty()) return fail(h, BA_ERR_STATE, "comm_init: a pose prior is set, which several ranks do not support");
   h->rccl = rccl_load();
   if (!h->rccl) return fail(h, BA_ERR_DEVICE, "librccl.so could not be loaded: %s", dlerror());
   HIP_TRY(h, hipSetDevice(h->device));
@@ -939,6 +955,13 @@ int validate_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
     if (!std::isfinite(obs_uv[2 * (size_t)k]) || !std::isfinite(obs_uv[2 * (size_t)k + 1]))
       return fail(h, BA_ERR_INVALID, "observation %d is not finite", k);
   }
+  if (!h->prior.cams.empty()) {
+    if (h->world > 1) return fail(h, BA_ERR_STATE, "set_problem: a pose prior is set, which several ranks do not support");
+    for (int c : h->prior.cams) {
+      if (c >= C) return fail(h, BA_ERR_INVALID, "pose prior: camera %d is not a camera of this problem (C=%d)", c, C);
+      if (fixed_in ? fixed_in[c] != 0 : c == 0) return fail(h, BA_ERR_INVALID, "pose prior: camera %d is fixed", c);
+    }
+  }
   if (fixed_in) {
     int nfree = 0;
     for (int c = 0; c < C; ++c) nfree += fixed_in[c] ? 0 : 1;
@@ -951,6 +974,45 @@ int validate_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
 }  // namespace
 
 extern "C" {
+
+int ba_set_pose_prior(ba_handle* h, int32_t n_prior, const int32_t* cams, const double* ref_poses, const double* H,
+                      const double* g, double c0) {
+  if (!h) return BA_ERR_INVALID;
+  if (n_prior < 0 || n_prior > BA_PRIOR_MAX_CAMS)
+    return fail(h, BA_ERR_INVALID, "pose prior: %d cameras (at most %d)", n_prior, BA_PRIOR_MAX_CAMS);
+  if (n_prior > 0 && (!cams || !ref_poses || !H || !g)) return fail(h, BA_ERR_INVALID, "pose prior: null pointer");
+  if (n_prior > 0 && h->world > 1) return fail(h, BA_ERR_STATE, "pose prior: not available with several ranks");
+  const int n6 = 6 * n_prior;
+  for (int a = 0; a < n_prior; ++a) {
+    if (cams[a] < 0) return fail(h, BA_ERR_INVALID, "pose prior: camera index %d", cams[a]);
+    for (int b = 0; b < a; ++b)
+      if (cams[a] == cams[b]) return fail(h, BA_ERR_INVALID, "pose prior: camera %d appears twice", cams[a]);
+    double nq = 0.0;
+    for (int i = 0; i < 7; ++i) {
+      if (!std::isfinite(ref_poses[7 * a + i])) return fail(h, BA_ERR_INVALID, "pose prior: reference pose %d is not finite", a);
+      if (i >= 3) nq += ref_poses[7 * a + i] * ref_poses[7 * a + i];
+    }
+    if (std::fabs(std::sqrt(nq) - 1.0) > 1e-6) return fail(h, BA_ERR_INVALID, "pose prior: reference quaternion %d is not unit length", a);
+  }
+  for (int i = 0; i < n6; ++i) {
+    if (!std::isfinite(g[i])) return fail(h, BA_ERR_INVALID, "pose prior: g[%d] is not finite", i);
+    for (int j = 0; j < n6; ++j) {
+      const double v = H[(size_t)i * n6 + j], w = H[(size_t)j * n6 + i];
+      if (!std::isfinite(v)) return fail(h, BA_ERR_INVALID, "pose prior: H[%d][%d] is not finite", i, j);
+      if (std::fabs(v - w) > 1e-9 * (std::fabs(v) + std::fabs(w)) + 1e-300)
+        return fail(h, BA_ERR_INVALID, "pose prior: H is not symmetric at [%d][%d]", i, j);
+    }
+    if (H[(size_t)i * n6 + i] < 0.0) return fail(h, BA_ERR_INVALID, "pose prior: H[%d][%d] < 0", i, i);
+  }
+  if (!std::isfinite(c0)) return fail(h, BA_ERR_INVALID, "pose prior: c0 is not finite");
+  h->prior.cams.assign(cams, cams + n_prior);
+  h->prior.ref.assign(ref_poses, ref_poses + (size_t)7 * n_prior);
+  h->prior.H.assign(H, H + (size_t)n6 * n6);
+  h->prior.g.assign(g, g + n6);
+  h->prior.c0 = n_prior > 0 ? c0 : 0.0;
+  free_problem(h);  // the block pattern of a problem set earlier does not hold the prior's camera pairs
+  return BA_OK;
+}
 
 int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t* obs_cam, const int32_t* obs_pt,
                    const double* obs_uv, const double* intr, const uint8_t* fixed_in) {
@@ -1045,6 +1107,11 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
   // ---- block pattern of the reduced camera system (upper triangle over free cameras)
   std::vector<int64_t> keys;
   for (int f = 0; f < Cf; ++f) keys.push_back((int64_t)f * Cf + f);
+  for (int a : h->prior.cams)  // the prior couples its cameras with each other, landmarks in common or not
+    for (int b : h->prior.cams) {
+      const int fa = h->cam2free[a], fb = h->cam2free[b];
+      if (fa < fb) keys.push_back((int64_t)fa * Cf + fb);
+    }
   {
     std::vector<int> prev, cur;
     for (int j = 0; j < L_obs; ++j) {
@@ -1677,6 +1744,23 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
         (rc = dev_upload(h, &h->bcr_cam0, h->h_bcam0)) || (rc = dev_upload(h, &h->bcr_cnt, h->h_bcnt)))
       return rc;
   }
+  d.prior = PriorDev{};
+  if (!h->prior.cams.empty()) {
+    const int np = (int)h->prior.cams.size();
+    std::vector<int> fr(np), slot((size_t)np * np, -1);
+    for (int a = 0; a < np; ++a) fr[a] = h->cam2free[h->prior.cams[a]];
+    for (int a = 0; a < np; ++a)
+      for (int b = 0; b < np; ++b)
+        if (fr[a] <= fr[b] && (a == b || fr[a] != fr[b]))
+          slot[(size_t)a * np + b] =
+              (int)(std::lower_bound(keys.begin(), keys.end(), (int64_t)fr[a] * Cf + fr[b]) - keys.begin());
+    if ((rc = dev_upload(h, &d.prior.cam, h->prior.cams)) || (rc = dev_upload(h, &d.prior.fr, fr)) ||
+        (rc = dev_upload(h, &d.prior.slot, slot)) || (rc = dev_upload(h, &d.prior.ref, h->prior.ref)) ||
+        (rc = dev_upload(h, &d.prior.H, h->prior.H)) || (rc = dev_upload(h, &d.prior.g, h->prior.g)))
+      return rc;
+    d.prior.n = np;
+    d.prior.c0 = h->prior.c0;
+  }
   h->dense_A = nullptr;
   if (h->dense_solve) {
     const size_t ld = (size_t)h->dense_nt * DT;
@@ -1749,6 +1833,7 @@ int ba_solve_batched(ba_handle* h, int32_t B, const int32_t* cam_off, const int3
                      const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_uv, const double* intr,
                      double* poses, double* points, double* cost0, double* cost, ba_report* report) {
   if (!h) return BA_ERR_INVALID;
+  if (!h->prior.cams.empty()) return fail(h, BA_ERR_STATE, "solve_batched: a pose prior is set (ba_set_pose_prior with n_prior = 0 removes it)");
   if (h->world > 1)  // windows are independent: ranks take disjoint sets of windows, each with a handle of its own
     return fail(h, BA_ERR_STATE, "solve_batched needs no communicator: use a handle without ba_comm_init per rank");
   if (B <= 0 || !cam_off || !lm_off || !obs_off || !obs_cam || !obs_pt || !obs_uv || !intr || !poses || !points)

@@ -70,6 +70,7 @@ _SIGNATURES = {
     "ba_destroy": (None, [_P]),
     "ba_last_error": (C.c_char_p, [_P]),
     "ba_set_problem": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _I, _I, _D, _D, C.POINTER(C.c_uint8)]),
+    "ba_set_pose_prior": (C.c_int, [_P, C.c_int32, _I, _D, _D, _D, C.c_double]),
     "ba_solve": (C.c_int, [_P, _D, _D, C.POINTER(BaReport)]),
     "ba_upload_guess": (C.c_int, [_P, _D, _D]),
     "ba_solve_resident": (C.c_int, [_P, C.POINTER(BaReport)]),
@@ -244,6 +245,22 @@ class Solver:
         self._check(self._lib.ba_set_problem(self._h, n_cams, n_pts, n, obs_cam.ctypes.data_as(_I),
                                              obs_pt.ctypes.data_as(_I), _dptr(obs_uv), _dptr(intr), fx))
         self.C, self.L, self.n = int(n_cams), int(n_pts), int(n)
+
+    PRIOR_MAX_CAMS = 16
+
+    def set_pose_prior(self, cams, ref_poses, H, g, c0: float = 0.0):
+        """Quadratic prior on the poses `cams` of the NEXT set_problem (ba_set_pose_prior; cams=None or empty removes
+        it): E = c0 + g^T d + 0.5 d^T H d over the chart coordinates d of those poses around ref_poses."""
+        n = 0 if cams is None else len(cams)
+        if n == 0:
+            self._check(self._lib.ba_set_pose_prior(self._h, 0, None, None, None, None, 0.0))
+            return
+        cams = np.ascontiguousarray(cams, dtype=np.int32)
+        ref = _f64(ref_poses, (n, 7))
+        H = _f64(H, (6 * n, 6 * n))
+        g = _f64(g, (6 * n,))
+        self._check(self._lib.ba_set_pose_prior(self._h, n, cams.ctypes.data_as(_I), _dptr(ref), _dptr(H), _dptr(g),
+                                                float(c0)))
 
     def _state(self, poses, points):
         return _f64(poses, (self.C, 7)).copy(), _f64(points, (self.L, 3)).copy()

@@ -10,6 +10,13 @@ keyframes, and solves ALL windows in one GPU call as one block-diagonal problem 
 window on the reduced camera system, csrc/ba_kernels.h: k_solve_components).  The oldest ``n_fixed``
 keyframes of a window are held constant: a hard prior in place of marginalisation (the reference fixes
 image 0 the same way, bundle_adjustment.py:51-52).  No CPU fallback.
+
+``SlidingWindowBundleAdjustment`` is the sequential variant with a marginalisation prior: windows are solved in
+order, and what a window knows about the keyframes it is about to drop (their observations, and those of every map
+point they see) is kept as a quadratic prior on the remaining keyframes (include/ba_amd.h: ba_set_pose_prior); the
+map points that went into the prior are frozen.  The first ``n_fixed`` keyframes of the list are held constant wherever
+they appear (two by default: six degrees of freedom and the monocular scale; with one, the scale stays a free gauge
+that every prior inherits as a null direction, and the chain of windows does not converge).
 """
 
 from __future__ import annotations
@@ -156,3 +163,131 @@ class LocalBundleAdjustment:
             out_pts[w.landmark_rows] = X[lm_off[b]: lm_off[b + 1]]
         return ([CameraPose(position=p[:3], orientation=p[3:7], timestamp=k.timestamp)
                  for p, k in zip(out_poses, keyframes)], out_pts)
+
+
+def _chart(poses: np.ndarray, ref: np.ndarray) -> np.ndarray:
+    """Coordinates of `poses` in the chart of the solver's retraction around `ref` (ba_set_pose_prior's d), n x 6."""
+    rw, rv = ref[:, 3:4], ref[:, 4:7]
+    qw, qv = poses[:, 3:4], poses[:, 4:7]
+    w = rw * qw + np.sum(rv * qv, axis=1, keepdims=True)          # conj(ref) (x) q
+    v = rw * qv - qw * rv - np.cross(rv, qv)
+    return np.hstack([poses[:, :3] - ref[:, :3], 2.0 * v / w])
+
+
+@dataclass
+class WindowPrior:
+    keyframes: np.ndarray  # indices into the keyframe list
+    ref: np.ndarray        # n x 7 chart origins (the estimates at marginalisation time)
+    H: np.ndarray          # 6n x 6n
+    g: np.ndarray          # 6n
+    c0: float
+
+    def energy(self, poses: np.ndarray) -> float:
+        d = _chart(poses, self.ref).reshape(-1)
+        return self.c0 + float(d @ (self.g + 0.5 * (self.H @ d)))
+
+
+class SlidingWindowBundleAdjustment:
+    """Fixed-lag smoothing over a keyframe list: windows [s, s + window), s = 0, stride, 2 stride, ..., solved one
+    after the other on the GPU; the keyframes that leave a window are marginalised into a prior on the ones that stay."""
+
+    def __init__(self, window: int = 10, stride: int = 1, min_views: int = 2, n_fixed: int = 2,
+                 **solver_options) -> None:
+        if window - stride > _native.Solver.PRIOR_MAX_CAMS:
+            raise ValidationError(f"a prior holds at most {_native.Solver.PRIOR_MAX_CAMS} keyframes")
+        if n_fixed < 1 or n_fixed >= window:
+            raise ValidationError("between 1 and window - 1 keyframes at the head of the list must be fixed (gauge)")
+        self.window, self.stride, self.min_views, self.n_fixed = window, stride, min_views, n_fixed
+        self.solver_options = solver_options
+        self.last_windows: List[Window] = []
+        self.last_reports: List[dict] = []
+        self.last_priors: List[Optional[WindowPrior]] = []  # the prior each window was solved WITH
+        self.last_frozen: List[np.ndarray] = []             # map rows frozen after each window
+
+    def _marginalize(self, w: Window, P: np.ndarray, X: np.ndarray, intr: np.ndarray, fixed: np.ndarray,
+                     prior: Optional[WindowPrior], n_drop: int) -> Tuple[Optional[WindowPrior], np.ndarray]:
+        """The factor that the first n_drop keyframes of window w leave behind, at the window's estimate (P, X).  The
+        reduced camera system of the sub-problem (the map points those keyframes see + the window's own prior) comes
+        from the GPU (lambda = 0); the dropped free keyframes are then eliminated from it here (a 6n x 6n system)."""
+        C = len(w.keyframes)
+        drop = np.zeros(C, bool)
+        drop[:n_drop] = True
+        lm_drop = np.zeros(len(w.landmark_ids), bool)
+        lm_drop[w.obs_pt[drop[w.obs_cam]]] = True
+        rows = np.flatnonzero(lm_drop)
+        if len(rows) == 0:
+            return None, rows
+        sel = lm_drop[w.obs_pt]
+        remap = np.full(len(lm_drop), -1, dtype=np.int32)
+        remap[rows] = np.arange(len(rows), dtype=np.int32)
+        with _native.Solver(**self.solver_options) as s:
+            if prior is not None:
+                local = np.searchsorted(w.keyframes, prior.keyframes)
+                s.set_pose_prior(local, prior.ref, prior.H, prior.g, prior.c0)
+            s.set_problem(C, len(rows), w.obs_cam[sel], remap[w.obs_pt[sel]], w.obs_uv[sel], intr, fixed=fixed)
+            lin = s.debug_linearization(P, X[rows], 0.0)
+            _, cost, _ = s.evaluate(P, X[rows], want_residuals=False)
+        S, b = lin["S"], lin["rhs"]
+        free = fixed == 0
+        fm = np.repeat(free, 6)
+        S[np.ix_(~fm, ~fm)] = 0.0  # the export's identity rows of the fixed keyframes
+        c = cost - 0.5 * float(np.einsum("li,li->", lin["gp"], np.linalg.solve(lin["V"], lin["gp"][:, :, None])[:, :, 0]))
+        if prior is not None:
+            c += prior.energy(P[np.searchsorted(w.keyframes, prior.keyframes)])
+        blocks = np.abs(S).reshape(C, 6, C, 6).sum(axis=(1, 2, 3)) + np.abs(b).reshape(C, 6).sum(axis=1)
+        touched = blocks > 0.0
+        keep = np.flatnonzero(~drop & free & touched)
+        elim = np.flatnonzero(drop & free & touched)
+        if len(keep) == 0:
+            return None, rows
+        ik = (6 * keep[:, None] + np.arange(6)).reshape(-1)
+        H, g = S[np.ix_(ik, ik)], b[ik]
+        if len(elim):
+            ie = (6 * elim[:, None] + np.arange(6)).reshape(-1)
+            sol = np.linalg.solve(S[np.ix_(ie, ie)], np.column_stack([S[np.ix_(ie, ik)], b[ie]]))
+            H = H - S[np.ix_(ik, ie)] @ sol[:, :-1]
+            g = g - S[np.ix_(ik, ie)] @ sol[:, -1]
+            c -= 0.5 * float(b[ie] @ sol[:, -1])
+        return WindowPrior(keyframes=w.keyframes[keep], ref=P[keep].copy(), H=0.5 * (H + H.T), g=g, c0=c), rows
+
+    def optimize(self, keyframes: Sequence[Keyframe], points_3d: np.ndarray, points_3d_ids: np.ndarray,
+                 camera_matrix: np.ndarray, intrinsics: Optional[np.ndarray] = None
+                 ) -> Tuple[List[CameraPose], np.ndarray]:
+        points = np.array(points_3d, dtype=float).reshape(-1, 3)
+        intr = LocalBundleAdjustment._intrinsics(camera_matrix) if intrinsics is None else np.asarray(intrinsics, dtype=float)
+        wins = build_windows(keyframes, points_3d_ids, self.window, self.stride, self.min_views)
+        poses = np.array([np.concatenate([k.pose.position, k.pose.quaternion]) for k in keyframes]).reshape(-1, 7)
+        poses[:, 3:7] /= np.linalg.norm(poses[:, 3:7], axis=1, keepdims=True)
+        frozen = np.zeros(len(points), bool)
+        prior: Optional[WindowPrior] = None
+        self.last_windows, self.last_reports, self.last_priors, self.last_frozen = [], [], [], []
+        for b, w in enumerate(wins):
+            # the window without the frozen map points (their information is in the prior)
+            live = ~frozen[w.landmark_rows]
+            sel = live[w.obs_pt]
+            remap = (np.cumsum(live) - 1).astype(np.int32)
+            w = Window(first=w.first, keyframes=w.keyframes, landmark_ids=w.landmark_ids[live],
+                       landmark_rows=w.landmark_rows[live], obs_cam=w.obs_cam[sel], obs_pt=remap[w.obs_pt[sel]],
+                       obs_uv=w.obs_uv[sel])
+            C = len(w.keyframes)
+            fixed = (w.keyframes < self.n_fixed).astype(np.uint8)
+            if prior is None and not fixed.any():
+                fixed[0] = 1  # nothing anchors this window (no map point links it to the ones before)
+            with _native.Solver(**self.solver_options) as s:
+                if prior is not None:
+                    s.set_pose_prior(np.searchsorted(w.keyframes, prior.keyframes), prior.ref, prior.H, prior.g, prior.c0)
+                s.set_problem(C, len(w.landmark_ids), w.obs_cam, w.obs_pt, w.obs_uv, intr, fixed=fixed)
+                P, X, rep = s.solve(poses[w.keyframes], points[w.landmark_rows])
+            poses[w.keyframes] = P
+            points[w.landmark_rows] = X
+            self.last_windows.append(w)
+            self.last_reports.append(rep)
+            self.last_priors.append(prior)
+            if b + 1 < len(wins):
+                n_drop = int(np.searchsorted(w.keyframes, wins[b + 1].first))
+                new_prior, rows = self._marginalize(w, P, X, intr, fixed, prior, n_drop)
+                frozen[w.landmark_rows[rows]] = True
+                prior = new_prior
+            self.last_frozen.append(np.flatnonzero(frozen))
+        return ([CameraPose(position=p[:3], orientation=p[3:7], timestamp=k.timestamp)
+                 for p, k in zip(poses, keyframes)], points)
