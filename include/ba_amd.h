@@ -193,9 +193,12 @@ int ba_download_estimate(ba_handle* h, double* poses, double* points);
  * cameras [cam_off[b], cam_off[b+1]), landmarks [lm_off[b], lm_off[b+1]) and observations
  * [obs_off[b], obs_off[b+1]); obs_cam / obs_pt are indices LOCAL to the observation's problem; the
  * first camera of every problem is held fixed; one camera model for all.  poses[cam_off[B]*7] and
- * points[lm_off[B]*3] are in/out.  All windows are solved together as one block-diagonal problem
- * (one LM damping sequence and one accept/reject decision for the batch; the reduced camera system
- * is solved exactly, one dense Cholesky per window).  cost0 / cost (may be NULL) receive each
+ * points[lm_off[B]*3] are in/out.  All windows are solved together as one block-diagonal problem: the
+ * streaming kernels run once over the whole batch, the reduced camera system is solved exactly (one dense
+ * Cholesky per window), and every window (connected component of the camera graph) has its own LM damping
+ * sequence, its own accept / reject decisions and its own ftol test: a window that rejects a step or has
+ * converged does not hold the others back, and the batch ends when every window has (status 2) or at max_iters.
+ * (Tracks longer than 32 observations fall back to one damping sequence for the batch.)  cost0 / cost (may be NULL) receive each
  * problem's 0.5 * sum r^2 before / after; report (may be NULL) describes the batch.  Leaves the
  * handle set to the concatenated problem. */
 int ba_solve_batched(ba_handle* h, int32_t n_problems, const int32_t* cam_off, const int32_t* lm_off,

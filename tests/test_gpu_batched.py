@@ -110,6 +110,48 @@ def test_batched_windows_match_individual_solves():
     assert abs(cost[0] - cost_o) <= 1e-6 * cost_o
 
 
+def test_batched_windows_keep_their_own_damping(monkeypatch):
+    """Levenberg-Marquardt per window (CompLm): every window of a batch has its own damping sequence and its own
+    accept / reject decisions, so the batch is B independent solves that share their launches.  Five ordinary windows
+    and one whose guess is far off (rejected steps, damping raised): every window must land where its own solve
+    (same exact reduced solver) lands, to 1e-9 in cost, the batch must take exactly as many iterations as its slowest
+    window alone; with ONE damping for the batch (BA_COMP_LM=0, the round-1 behaviour) the minima are the same (1e-6)
+    and the road is no shorter."""
+    seeds, sizes = [0, 1, 2, 3, 4, 5], [120, 80, 200, 120, 100, 150]
+    probs, scs = zip(*[_window(s, L=l) for s, l in zip(seeds, sizes)])
+    probs = [dict(p) for p in probs]
+    rng = np.random.default_rng(42)
+    far = np.asarray(probs[3]["poses"]).copy()
+    far[1:, :3] += 0.25 * rng.normal(size=(len(far) - 1, 3))
+    q = far[1:, 3:7] + 0.08 * rng.normal(size=(len(far) - 1, 4))
+    far[1:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    probs[3]["poses"] = far
+    probs[3]["points"] = np.asarray(probs[3]["points"]) + 1.0 * rng.normal(size=np.asarray(probs[3]["points"]).shape)
+    intr = scs[0]["intr"]
+    solo = []
+    for p in probs:
+        with _native.Solver(linear_solver=2) as s1:
+            s1.set_problem(len(p["poses"]), len(p["points"]), p["obs_cam"], p["obs_pt"], p["obs_uv"], intr)
+            solo.append(s1.solve(p["poses"], p["points"])[2])
+    assert all(r["status"] == 2 for r in solo)
+    its = [r["iterations"] for r in solo]
+    assert solo[3]["accepted"] < solo[3]["iterations"] and its[3] > max(its[:3] + its[4:])  # the far window struggles
+    with _native.Solver() as s:
+        P, X, cost0, cost, rep = s.solve_batched(probs, intr)
+    assert rep["status"] == 2 and rep["iterations"] == max(its), (rep["iterations"], its)
+    for b, r in enumerate(solo):
+        assert abs(cost0[b] - r["cost0"]) <= 1e-12 * r["cost0"]
+        assert abs(cost[b] - r["cost"]) <= 1e-9 * r["cost"], (b, cost[b], r["cost"])
+    assert abs(rep["cost"] - sum(r["cost"] for r in solo)) <= 1e-9 * rep["cost"]
+    assert abs(rep["cost0"] - sum(r["cost0"] for r in solo)) <= 1e-12 * rep["cost0"]
+    monkeypatch.setenv("BA_COMP_LM", "0")
+    with _native.Solver() as s:
+        _, _, _, cost_shared, rep_shared = s.solve_batched(probs, intr)
+    assert rep_shared["iterations"] >= rep["iterations"], (rep_shared["iterations"], rep["iterations"])
+    for b, r in enumerate(solo):  # the same minima, by a longer road
+        assert abs(cost_shared[b] - r["cost"]) <= 1e-6 * r["cost"]
+
+
 def test_batched_rejects_bad_input():
     probs, scs = zip(*[_window(s) for s in (0, 1)])
     bad = dict(probs[1])

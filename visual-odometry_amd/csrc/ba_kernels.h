@@ -76,6 +76,23 @@ struct PriorDev {
   const double* g;     // [6n]
 };
 
+// Levenberg-Marquardt per connected component of the camera graph (batched windows: every window has its own
+// damping sequence and its own accept / reject decisions; k_lm_decide_comp, k_commit_comp).  All null: one damping
+// for the whole problem.
+constexpr int CL_STRIDE = 6;  // per-component statistics: 0 g.d + d^T H d / 2 | 2 trial cost | 3 trial behind | 4 bad pivot
+struct CompLm {
+  double* lam;          // [n_comp]
+  double* nu;           // [n_comp]
+  double* cost;         // [n_comp] cost of the component at the current estimate
+  double* nbehind;      // [n_comp]
+  double* stat;         // [n_comp][CL_STRIDE]
+  int* accept;          // [n_comp] decision of the last iteration
+  int* done;            // [n_comp] converged (or given up): the component is frozen
+  double* lam_lm;       // [L_obs] damping per landmark (= lam[lm_comp]): what the streaming kernels load
+  const int* lm_comp;   // [L_obs]
+  const int* free_comp; // [Cf]
+};
+
 struct DeviceProblem {
   int C, Cf, L, L_obs, n;  // cameras, free cameras, landmarks, landmarks with >= 1 observation, observations
   Intrinsics K;
@@ -134,6 +151,7 @@ struct DeviceProblem {
   LmCtrl* ctrl;
   double* poses_buf[2]; double* pts_buf[2];
   PriorDev prior;
+  CompLm clm;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1062,6 +1080,7 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
   __shared__ int sFree[SCH_CAP];
   __shared__ int sKb[SCH_MAXLM + 1];
   __shared__ int sTab[3][SCH_MAXCPB + 1];  // this block's chunks: first landmark | first observation | flush bits
+  const bool per_comp = lam < 0.0 && d.clm.lam_lm != nullptr;  // solver mode with a damping per component
   if (lam < 0.0) {  // solver mode
     if (d.ctrl->done) return;
     lam = d.ctrl->lam;
@@ -1127,7 +1146,7 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
 
   // registers of the chunk in flight (raw loaded values only: arithmetic on them would make the
   // compiler wait for the loads right here)
-  double pw[18], pv[6], pg[3];
+  double pw[18], pv[6], pg[3], plam = 0.0;
   int pfree = -1, plm = 0, pkb = 0, p_j0 = 0, p_k0 = 0, p_nobs = 0, p_nc = 0;
   auto issue = [&](int ci) {
     const int j0 = sTab[0][ci - c0], j1 = sTab[0][ci - c0 + 1], k0 = sTab[1][ci - c0], k1 = sTab[1][ci - c0 + 1];
@@ -1146,6 +1165,7 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
       for (int i = 0; i < 6; ++i) pv[i] = d.V[(long)i * L + j0 + lane];
 #pragma unroll
       for (int i = 0; i < 3; ++i) pg[i] = d.gp[(long)i * L + j0 + lane];
+      if (per_comp) plam = d.clm.lam_lm[j0 + lane];
     }
     if (lane <= p_nc) pkb = d.lm_ptr[j0 + lane];
   };
@@ -1162,7 +1182,7 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
     __syncthreads();  // the pairs of the previous chunk are done with the LDS tiles
     if (lane < nc) {
       double vi[6];
-      const double det = damped_inv3(pv, lam, min_diag, vi);
+      const double det = damped_inv3(pv, per_comp ? plam : lam, min_diag, vi);
       if (!(det > 0.0)) ++nbad;
 #pragma unroll
       for (int i = 0; i < 6; ++i) sVi[lane * 9 + i] = vi[i];
@@ -1720,12 +1740,21 @@ constexpr int COMP_MAX_CAMS = 12;
 
 __global__ __launch_bounds__(64) void k_solve_components(DeviceProblem d, double lam, double min_diag) {
   extern __shared__ double sm[];
+  const bool per_comp = lam < 0.0 && d.clm.lam != nullptr;
   if (lam < 0.0) {
     if (d.ctrl->done) return;
     lam = d.ctrl->lam;
   }
   const int comp = blockIdx.x, lane = threadIdx.x;
   const int c0 = d.comp_ptr[comp], nc = d.comp_ptr[comp + 1] - c0, n = 6 * nc, ld = n + 1;
+  if (per_comp) {  // a damping per component; a frozen component takes no step
+    lam = d.clm.lam[comp];
+    if (d.clm.done[comp]) {
+      for (int t = lane; t < n; t += 64) d.dc[6L * d.comp_cams[c0 + t / 6] + t % 6] = 0.0;
+      if (lane == 0 && comp == 0) { d.scal[SC_PCGIT] = 0.0; d.scal[SC_DONE] = 1.0; }
+      return;
+    }
+  }
   double* A = sm;            // [n][ld] lower triangle used
   double* b = sm + n * ld;   // [n]
   for (int t = lane; t < n * ld; t += 64) A[t] = 0.0;
@@ -1786,7 +1815,10 @@ __global__ __launch_bounds__(64) void k_solve_components(DeviceProblem d, double
     d.dc[6L * f + t % 6] = b[t];
   }
   if (lane == 0) {
-    if (bad) atomic_add_f64(&SCAL_MINE(d)[SC_BADV], 1.0);
+    if (bad) {
+      if (per_comp) d.clm.stat[CL_STRIDE * comp + 4] = 1.0;  // only this component's step is refused
+      else atomic_add_f64(&SCAL_MINE(d)[SC_BADV], 1.0);
+    }
     if (comp == 0) { d.scal[SC_PCGIT] = 0.0; d.scal[SC_DONE] = 1.0; }
   }
 }
@@ -1838,6 +1870,9 @@ __device__ __forceinline__ void pose_update_block(const DeviceProblem& d, const 
 #pragma unroll
       for (int i = 0; i < 7; ++i) pt[i] = po[i];
       xn = ps[0] * ps[0] + ps[1] * ps[1] + ps[2] * ps[2] + 1.0;
+      if (d.clm.lam) {
+        atomic_add_f64(&d.clm.stat[(long)CL_STRIDE * d.clm.free_comp[f]], gd + 0.5 * dhd);
+      }
     }
   }
   const double b0 = block_sum_256(gd, red), b1 = block_sum_256(dhd, red), b2 = block_sum_256(dn, red),
@@ -1979,6 +2014,21 @@ __global__ __launch_bounds__(256) void k_backsub(DeviceProblem d, double lam, do
 // camera; it is skipped whenever |dp| < (1 - GUARD_KEEP) zmin (zmin: the landmark's smallest depth, left by the
 // linearisation), which cannot cross a principal plane: the test then costs 8 B per landmark.
 // Algorithmic bytes: those of k_backsub + k_cost minus the second read of the points: 172 B/obs + 152 B/landmark.
+// Add v of every active lane into statistic `slot` of the lane's component: one atomic per wave when the active lanes
+// agree on the component (the usual case: a chunk of 64 observations inside one window), one per lane otherwise.
+// Wave-uniform call.
+__device__ __forceinline__ void comp_add(double* __restrict__ stat, int slot, int comp, bool act, double v) {
+  const unsigned long long m = __ballot(act);
+  if (m == 0) return;
+  const int first = __builtin_amdgcn_readlane(comp, __ffsll((long long)m) - 1);
+  if (__ballot(act && comp != first) == 0) {
+    const double s = wave_sum_dpp(act ? v : 0.0);
+    if ((threadIdx.x & 63) == 0) atomic_add_f64(&stat[(long)CL_STRIDE * first + slot], s);
+  } else if (act) {
+    atomic_add_f64(&stat[(long)CL_STRIDE * comp + slot], v);
+  }
+}
+
 template <bool ROBUST>
 __global__ __launch_bounds__(256) void k_backsub_flat(DeviceProblem d, double lam, double min_diag,
                                                       const double* __restrict__ pts, double* __restrict__ pts_t,
@@ -1987,6 +2037,8 @@ __global__ __launch_bounds__(256) void k_backsub_flat(DeviceProblem d, double la
   __shared__ double red[4];
   __shared__ double sT[4][64 * 3];
   __shared__ double sPt[4][LINF_MAXLM * 3];
+  __shared__ int sComp[4][LINF_MAXLM];
+  const bool per_comp = lam < 0.0 && d.clm.lam != nullptr;  // solver mode with a damping and a decision per component
   if (lam < 0.0) {
     const LmCtrl* c = d.ctrl;
     if (c->done) return;
@@ -2025,6 +2077,8 @@ __global__ __launch_bounds__(256) void k_backsub_flat(DeviceProblem d, double la
   const long j = jb + lane;
   int tb = 0, te = 0;
   double V6[6] = {1, 0, 0, 1, 0, 1}, g[3] = {0, 0, 0}, P[3] = {0, 0, 0}, zmn = 0.0;
+  int cj = 0;
+  if (lm_lane && per_comp) { lam = d.clm.lam_lm[j]; cj = d.clm.lm_comp[j]; }
   if (lm_lane) {
     tb = d.lm_ptr[j] - kb; te = d.lm_ptr[j + 1] - kb;
 #pragma unroll
@@ -2085,6 +2139,7 @@ __global__ __launch_bounds__(256) void k_backsub_flat(DeviceProblem d, double la
     const double Pt[3] = {P[0] + dp[0], P[1] + dp[1], P[2] + dp[2]};
     pts_t[3 * j] = Pt[0]; pts_t[3 * j + 1] = Pt[1]; pts_t[3 * j + 2] = Pt[2];
     myP[3 * lane] = Pt[0]; myP[3 * lane + 1] = Pt[1]; myP[3 * lane + 2] = Pt[2];
+    sComp[wave][lane] = cj;
     gd = g[0] * dp[0] + g[1] * dp[1] + g[2] * dp[2];
     const double vdp0 = V6[0] * dp[0] + V6[1] * dp[1] + V6[2] * dp[2];
     const double vdp1 = V6[1] * dp[0] + V6[3] * dp[1] + V6[4] * dp[2];
@@ -2093,6 +2148,7 @@ __global__ __launch_bounds__(256) void k_backsub_flat(DeviceProblem d, double la
     dn = dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];
     xn = P[0] * P[0] + P[1] * P[1] + P[2] * P[2];
   }
+  if (per_comp) comp_add(d.clm.stat, 0, cj, lm_lane, gd + 0.5 * dhd);
   double cost = 0.0;
   int nbehind = 0, nzero = 0;
   if (with_cost) {
@@ -2113,6 +2169,11 @@ __global__ __launch_bounds__(256) void k_backsub_flat(DeviceProblem d, double la
       nbehind = X[2] <= 0.0;
       nzero = X[2] == 0.0;
       cost = !ROBUST ? 0.5 * (r0 * r0 + r1 * r1) : robust_cost(d.loss, r0) + robust_cost(d.loss, r1);
+    }
+    if (per_comp) {
+      const int co = act ? sComp[wave][lm - jb] : 0;
+      comp_add(d.clm.stat, 2, co, act, cost);
+      if (__ballot(act && nbehind != 0) != 0) comp_add(d.clm.stat, 3, co, act, (double)nbehind);
     }
   }
   const double b0 = block_sum_256(gd, red), b1 = block_sum_256(dhd, red), b2 = block_sum_256(dn, red),
@@ -2296,4 +2357,213 @@ __global__ __launch_bounds__(256) void k_lm_decide(DeviceProblem d, const double
   }
   *static_cast<LmHead*>(c) = h;
   lm_publish(mirror, h, seq);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Levenberg-Marquardt per connected component (CompLm): batched windows no longer share one damping sequence and one
+// accept / reject decision.  Per LM iteration, after the trial kernels: k_lm_decide_comp (one workgroup: every
+// component's gain ratio, decision and Nielsen update from its own statistics; the problem is done when every
+// component is) and k_commit_comp (accepted components copy their trial poses / points into the current buffers, every
+// landmark gets its component's new damping).  The current estimate stays in buffer 0 and every iteration linearises.
+// A component is frozen once an accepted step gains less than ftol of its cost (or its damping hits lambda_max).
+
+__global__ __launch_bounds__(256) void k_comp_init(DeviceProblem d, double lambda0) {
+  const CompLm& c = d.clm;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < max(d.L_obs, d.n_comp); t += gridDim.x * blockDim.x) {
+    if (t < d.L_obs) c.lam_lm[t] = lambda0;
+    if (t < d.n_comp) {
+      c.lam[t] = lambda0; c.nu[t] = 2.0; c.cost[t] = 0.0; c.nbehind[t] = 0.0; c.accept[t] = 0; c.done[t] = 0;
+#pragma unroll
+      for (int i = 0; i < CL_STRIDE; ++i) c.stat[(long)CL_STRIDE * t + i] = 0.0;
+    }
+  }
+}
+
+// cost and cheirality count of every component at (poses, pts): a lane per observation
+template <bool ROBUST>
+__global__ __launch_bounds__(256) void k_comp_cost(DeviceProblem d, const double* __restrict__ poses,
+                                                   const double* __restrict__ pts, double* __restrict__ cost_out,
+                                                   double* __restrict__ behind_out) {
+  for (long k0 = (long)blockIdx.x * blockDim.x; k0 < d.n; k0 += (long)gridDim.x * blockDim.x) {
+    const long k = k0 + threadIdx.x;
+    const bool act = k < d.n;
+    double cost = 0.0, nb = 0.0;
+    int comp = 0;
+    if (act) {
+      const int cam = d.o_cam[k], lm = d.o_lm[k];
+      comp = d.clm.lm_comp[lm];
+      const double* ps = poses + 7 * cam;
+      const double P[3] = {pts[3L * lm], pts[3L * lm + 1], pts[3L * lm + 2]};
+      double R[9], X[3], r0, r1;
+      quat_to_R(ps + 3, R);
+      to_camera(R, ps, P, X);
+      reproject(d.K, X, d.o_u[k], d.o_v[k], r0, r1);
+      nb = X[2] <= 0.0 ? 1.0 : 0.0;
+      cost = !ROBUST ? 0.5 * (r0 * r0 + r1 * r1) : robust_cost(d.loss, r0) + robust_cost(d.loss, r1);
+    }
+    // CL_STRIDE-strided adds into plain arrays: slot 0 of a stride-1 "statistic"
+    const unsigned long long m = __ballot(act);
+    if (m == 0) continue;
+    const int first = __builtin_amdgcn_readlane(comp, __ffsll((long long)m) - 1);
+    if (__ballot(act && comp != first) == 0) {
+      const double s = wave_sum_dpp(cost), b = wave_sum_dpp(nb);
+      if ((threadIdx.x & 63) == 0) { atomic_add_f64(&cost_out[first], s); if (b != 0.0) atomic_add_f64(&behind_out[first], b); }
+    } else if (act) {
+      atomic_add_f64(&cost_out[comp], cost);
+      if (nb != 0.0) atomic_add_f64(&behind_out[comp], nb);
+    }
+  }
+}
+
+constexpr int DECIDE_COMP_THREADS = 1024;
+__global__ __launch_bounds__(DECIDE_COMP_THREADS) void k_lm_decide_comp(DeviceProblem d, LmMirror* mirror, int seq) {
+  LmCtrl* c = d.ctrl;
+  if (c->done) {
+    if (threadIdx.x == 0) lm_publish(mirror, *static_cast<const LmHead*>(c), seq);
+    return;
+  }
+  __shared__ double part[8][SC_COUNT];
+  __shared__ double s[SC_COUNT];
+  __shared__ double red[5][DECIDE_COMP_THREADS / 64];
+  const int t = threadIdx.x;
+  const CompLm& q = d.clm;
+  // everything this thread's first component needs and the control head, requested before the fold of the global
+  // statistics: one round trip for all of it instead of three in a row
+  struct CompIn { double st0, cost_t, behind_t, badp, behind, cost, lam, nu; int done; };
+  auto load_comp = [&](int w) {
+    const double* st = q.stat + (long)CL_STRIDE * w;
+    return CompIn{st[0], st[2], st[3], st[4], q.nbehind[w], q.cost[w], q.lam[w], q.nu[w], q.done[w]};
+  };
+  CompIn in0{};
+  if (t < d.n_comp) in0 = load_comp(t);
+  const LmHead h0 = *static_cast<const LmHead*>(c);
+  if (t < 256) {  // the global statistics (gradient norms, step norms, counters): folded and cleared as k_lm_decide does
+    const int i = t & (SC_COUNT - 1), g = t / SC_COUNT;
+    const bool is_max = (i == SC_GINF || i == SC_GINF_C);
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < SCAL_SLABS / 8; ++k) {
+      const double x = d.scal[(size_t)(g * (SCAL_SLABS / 8) + k) * SC_COUNT + i];
+      v = is_max ? fmax(v, x) : v + x;
+    }
+    if (i < SC_NSUM) {
+#pragma unroll
+      for (int k = 0; k < SCAL_SLABS / 8; ++k) d.scal[(size_t)(g * (SCAL_SLABS / 8) + k) * SC_COUNT + i] = 0.0;
+    }
+    part[g][i] = v;
+  }
+  __syncthreads();
+  if (t < SC_NSUM) {
+    const bool is_max = (t == SC_GINF || t == SC_GINF_C);
+    double v = part[0][t];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v = is_max ? fmax(v, part[k][t]) : v + part[k][t];
+    s[t] = v;
+  }
+  __syncthreads();
+  const bool landmark_bad = s[SC_BADV] > 0.0;  // a landmark block that was not positive definite: nobody's step is trusted
+  double cost_sum = 0.0, cost_before = 0.0, n_acc = 0.0, n_done = 0.0;
+  int rejected_guard = 0;
+  for (int w = t; w < d.n_comp; w += DECIDE_COMP_THREADS) {
+    double* st = q.stat + (long)CL_STRIDE * w;
+    const CompIn in = w == t ? in0 : load_comp(w);
+    const double st0 = in.st0, cost_t = in.cost_t, behind_t = in.behind_t, badp = in.badp, behind = in.behind;
+    double cost = in.cost, lam = in.lam, nu = in.nu;
+    int done = in.done, accept = 0;
+    cost_before += cost;
+    if (!done) {
+      const double pred = -st0;
+      double rho = (pred > 0.0 && isfinite(cost_t)) ? (cost - cost_t) / pred : -1.0;
+      if (h0.guard_cheirality && behind_t > behind) { rho = -1.0; ++rejected_guard; }
+      if (landmark_bad || badp > 0.0) rho = -1.0;
+      accept = rho > h0.accept_ratio;
+      if (accept) {
+        const double dF = cost - cost_t;
+        cost = cost_t;
+        q.nbehind[w] = behind_t;
+        const double tt = 2.0 * rho - 1.0;
+        lam = fmax(h0.lambda_min, lam * fmax(1.0 / 3.0, 1.0 - tt * tt * tt));
+        nu = 2.0;
+        if (dF <= h0.ftol * cost_t) done = 1;
+      } else {
+        if (lam >= h0.lambda_max) done = 1;  // no damping is large enough: give the component up
+        lam = fmin(h0.lambda_max, lam * nu);
+        nu *= 2.0;
+      }
+      q.lam[w] = lam; q.nu[w] = nu; q.cost[w] = cost; q.done[w] = done;
+    }
+    q.accept[w] = accept;
+#pragma unroll
+    for (int i = 0; i < CL_STRIDE; ++i) st[i] = 0.0;
+    cost_sum += cost; n_acc += accept; n_done += done;
+  }
+  cost_sum = wave_sum_dpp(cost_sum); n_acc = wave_sum_dpp(n_acc); n_done = wave_sum_dpp(n_done);
+  cost_before = wave_sum_dpp(cost_before);
+  const double gr = wave_sum_dpp((double)rejected_guard);
+  if ((t & 63) == 0) {
+    red[0][t >> 6] = cost_sum; red[1][t >> 6] = n_acc; red[2][t >> 6] = n_done; red[3][t >> 6] = gr; red[4][t >> 6] = cost_before;
+  }
+  __syncthreads();
+  if (t != 0) return;
+  double tot = 0.0, acc = 0.0, dn = 0.0, grj = 0.0, before = 0.0;
+  for (int k = 0; k < DECIDE_COMP_THREADS / 64; ++k) {
+    tot += red[0][k]; acc += red[1][k]; dn += red[2][k]; grj += red[3][k]; before += red[4][k];
+  }
+  LmHead h = h0;
+  const int it = ++h.it;
+  if (it == 1) {
+    h.cost0 = before;
+    if (s[SC_ZEROZ] > 0.0) { h.error = 1; h.done = 1; }
+    else if (!isfinite(before)) { h.error = 2; h.done = 1; }
+  }
+  h.linearizations++;
+  h.nbehind = s[SC_NBEHIND];
+  h.ginf_pts = s[SC_GINF];
+  h.ginf = fmax(s[SC_GINF], s[SC_GINF_C]);
+  h.shortened_steps += (int)fmin(s[SC_NSHORT], 1e9);
+  h.guard_rejections += grj > 0.0;
+  if (landmark_bad) h.bad_pivots += (int)fmin(s[SC_BADV], 1e9);
+  const int hi = h.n_hist < LM_HISTORY ? h.n_hist++ : LM_HISTORY - 1;
+  c->lam_hist[hi] = q.lam[0];
+  c->pcg_hist[hi] = 0;
+  c->acc_hist[hi] = acc > 0.0;
+  if (it - 1 < LM_ACC_BITS) c->acc_bits[(it - 1) >> 5] |= 1u << ((it - 1) & 31);  // every iteration linearises
+  c->trial_hist[hi] = tot;
+  c->rho_hist[hi] = acc;  // (components that accepted)
+  c->ginf_hist[hi] = h.ginf;
+  c->step_hist[hi] = sqrt(s[SC_DNORM2] + s[SC_DNORM2_C]);
+  if (!h.done) {
+    if (acc > 0.0) h.accepted++;
+    h.cost = tot;
+    h.lam = q.lam[0];
+    h.need_lin = 1;
+    if (h.ginf <= h.gtol) { h.status = 1; h.done = 1; }
+    else if (dn >= (double)d.n_comp) { h.status = 2; h.done = 1; }
+    else if (it >= h.max_iters) h.done = 1;
+  }
+  c->cost_hist[hi] = h.cost;
+  *static_cast<LmHead*>(c) = h;
+  lm_publish(mirror, h, seq);
+}
+
+__global__ __launch_bounds__(256) void k_commit_comp(DeviceProblem d) {
+  const CompLm& q = d.clm;
+  // No look at ctrl->done: the decision that ends the solve still has accepted steps to commit.  A launch enqueued
+  // after that finds the same flags and the same trial buffers (every kernel before it exits at once): the same copy.
+  double* __restrict__ P0 = d.poses_buf[0];
+  const double* __restrict__ P1 = d.poses_buf[1];
+  double* __restrict__ X0 = d.pts_buf[0];
+  const double* __restrict__ X1 = d.pts_buf[1];
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < max(d.L_obs, d.Cf); t += (long)gridDim.x * blockDim.x) {
+    if (t < d.L_obs) {
+      const int w = q.lm_comp[t];
+      if (q.accept[w]) { X0[3 * t] = X1[3 * t]; X0[3 * t + 1] = X1[3 * t + 1]; X0[3 * t + 2] = X1[3 * t + 2]; }
+      q.lam_lm[t] = q.lam[w];
+    }
+    if (t < d.Cf && q.accept[q.free_comp[t]]) {
+      const long cam = d.free2cam[t];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) P0[7 * cam + i] = P1[7 * cam + i];
+    }
+  }
 }

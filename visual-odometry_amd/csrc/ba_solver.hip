@@ -127,6 +127,7 @@ struct ba_handle {
   int schur_cpb = 0;  // > 0: k_schur_staged with this many chunks per block
   bool small_solve = false;
   bool comp_solve = false;  // dense Cholesky per connected component of the camera graph
+  bool comp_lm = false;     // ... and Levenberg-Marquardt per component (damping, accept / reject): CompLm
   size_t comp_lds = 0;
   bool dense_solve = false;  // whole-GPU dense Cholesky of the reduced system (ba_dense.h)
   bool banded_solve = false; // banded + arrow block Cholesky in one workgroup (ba_banded.h)
@@ -697,6 +698,15 @@ int lm_solve(ba_handle* h, ba_report* rep) {
     k_init_solve<<<(int)std::min<long>(1024, (work + 255) / 256), 256, 0, h->stream>>>(
         d, (const double*)h->poses_init, (const double*)h->pts_init, static_cast<const LmHead&>(c), n_clear);
     note_launch(h);
+    if (h->comp_lm) {
+      k_comp_init<<<std::min(1024, grid_for(std::max(d.L_obs, d.n_comp))), 256, 0, h->stream>>>(d, o.lambda0);
+      const int grid = std::min(grid_for(d.n), 256 * 16);
+      if (d.loss.kind == LOSS_LINEAR)
+        k_comp_cost<false><<<grid, 256, 0, h->stream>>>(d, (const double*)d.poses_buf[0], (const double*)d.pts_buf[0], d.clm.cost, d.clm.nbehind);
+      else
+        k_comp_cost<true><<<grid, 256, 0, h->stream>>>(d, (const double*)d.poses_buf[0], (const double*)d.pts_buf[0], d.clm.cost, d.clm.nbehind);
+      note_launch(h);
+    }
   }
 
   const int check_every =
@@ -719,7 +729,11 @@ int lm_solve(ba_handle* h, ba_report* rep) {
       int pcg_it = 0;
       if ((rc = do_reduced_solve(h, -1.0, &pcg_it))) return rc;
       enqueue_trial(h, -1.0, nullptr, nullptr, nullptr, nullptr);
-      if (h->world > 1) {
+      if (h->comp_lm) {
+        // every connected component decides for itself; the accepted ones move into the current buffers
+        launch_timed(h, KT_DECIDE, k_lm_decide_comp, 1, DECIDE_COMP_THREADS, d, h->mirror_dev, enq + 1);
+        launch_timed(h, KT_OTHER, k_commit_comp, std::min(2048, grid_for(std::max(d.L_obs, d.Cf))), 256, d);
+      } else if (h->world > 1) {
         // fold on the device, combine the ranks with one sum all-reduce (the max of the point-gradient norm
         // travels in per-rank slots)
         k_fold_scalars<<<1, 128, 0, h->stream>>>(d, h->scal_fold, h->rank, h->world); note_launch(h);
@@ -1375,6 +1389,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
 
   // connected components of the camera graph -> dense Cholesky per component when all are small
   std::vector<int> comp_ptr(1, 0), comp_cams(Cf), comp_local(Cf), comp_slot_ptr(1, 0), comp_slots(nu);
+  std::vector<int> free_comp;  // component of every free camera
   {
     std::vector<int> parent(Cf);
     std::iota(parent.begin(), parent.end(), 0);
@@ -1400,6 +1415,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
     std::vector<int> fill(comp_slot_ptr.begin(), comp_slot_ptr.end() - 1);
     for (int s2 = 0; s2 < nu; ++s2) comp_slots[fill[comp_id[urow[s2]]]++] = s2;
     h->d.n_comp = n_comp;
+    free_comp = comp_id;
     const int n = 6 * max_cams;
     h->comp_lds = ((size_t)n * (n + 1) + n) * sizeof(double);
     const int want = h->opt.linear_solver;
@@ -1409,6 +1425,10 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
     constexpr int DENSE_MAX_CAMS = 2048;
     const bool comps_small = Cf > 0 && max_cams <= COMP_MAX_CAMS && env_int("BA_COMP_SOLVE", 1);
     h->comp_solve = comps_small && (want == BA_SOLVER_DENSE_CHOLESKY || (want == BA_SOLVER_AUTO && n_comp > 1));
+    // independent components get independent LM sequences when every kernel of the iteration has its per-component
+    // form (staged Schur kernel, flat back-substitution, Cholesky per component), on one GPU, without a pose prior
+    h->comp_lm = h->comp_solve && n_comp > 1 && h->schur_cpb > 0 && h->flat_chunks > 0 && h->use_flat_backsub &&
+                 h->world == 1 && h->prior.cams.empty() && env_int("BA_COMP_LM", 1) != 0;
     if (want == BA_SOLVER_PCG || h->comp_solve) h->dense_solve = false;
     else if (want == BA_SOLVER_DENSE_CHOLESKY) h->dense_solve = true;
     else h->dense_solve = !h->small_solve && env_int("BA_DENSE_SOLVE", 1);
@@ -1742,6 +1762,20 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
         (rc = dev_upload(h, &h->bcr_dst2, h->h_bdst2)) || (rc = dev_upload(h, &h->bcr_kind, h->h_bkind)) ||
         (rc = dev_upload(h, &h->bcr_rdst, h->h_brdst)) || (rc = dev_upload(h, &h->bcr_pad, h->h_bpad)) ||
         (rc = dev_upload(h, &h->bcr_cam0, h->h_bcam0)) || (rc = dev_upload(h, &h->bcr_cnt, h->h_bcnt)))
+      return rc;
+  }
+  d.clm = CompLm{};
+  if (h->comp_lm) {
+    std::vector<int> lm_comp(L_obs, 0);
+    for (int j = 0; j < L_obs; ++j)
+      for (int k = lm_ptr[j]; k < lm_ptr[j + 1]; ++k)
+        if (o_free[k] >= 0) { lm_comp[j] = free_comp[o_free[k]]; break; }
+    const size_t nc = (size_t)d.n_comp;
+    if ((rc = dev_alloc(h, &d.clm.lam, nc)) || (rc = dev_alloc(h, &d.clm.nu, nc)) || (rc = dev_alloc(h, &d.clm.cost, nc)) ||
+        (rc = dev_alloc(h, &d.clm.nbehind, nc)) || (rc = dev_alloc(h, &d.clm.stat, nc * CL_STRIDE)) ||
+        (rc = dev_alloc(h, &d.clm.accept, nc)) || (rc = dev_alloc(h, &d.clm.done, nc)) ||
+        (rc = dev_alloc(h, &d.clm.lam_lm, (size_t)L_obs)) || (rc = dev_upload(h, &d.clm.lm_comp, lm_comp)) ||
+        (rc = dev_upload(h, &d.clm.free_comp, free_comp)))
       return rc;
   }
   d.prior = PriorDev{};
