@@ -124,6 +124,12 @@ struct DeviceProblem {
   int n_comp;
   const int* lin_lm;     // [n_lin_chunks + 1] first landmark of each k_linearize_flat chunk
   const int* lin_k;      // [n_lin_chunks + 1] first observation of each chunk
+  const unsigned char* lin_perm;  // [n] k_linearize_win: row of the observation when its chunk's free observations are put in camera order
+  const int* lin_gptr;   // [n_lin_chunks + 1] first entry of each chunk in the group tables (groups + 1 sentinel per chunk)
+  const int* lin_gbeg;   // [...] first position of each camera group of a chunk (sentinel: the chunk's free observations)
+  const int* lin_gcam;   // [...] the group's camera
+  const int* lin_gslot;  // [...] its slot in the workgroup's LDS copy of U | gc, or -1 (straight to the global slab)
+  const int* lin_wincam; // [workgroups][LINW_WIN] camera of each slot, -1 = unused
   int n_lin_chunks;      // 0: no chunk tables (some track is longer than LINF_MAXLM)
   int lin_flat;          // 1: k_linearize_flat takes the chunks (few cameras); k_backsub_flat takes them whenever they exist
   const int* sch_lm;     // [n_chunks + 1] first landmark of each k_schur_staged chunk
@@ -464,6 +470,190 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_f
   for (int i = tid; i < d.C * 27; i += 64 * LINF_WAVES) {
     const double x = sU[i];
     if (x != 0.0) atomic_add_f64(Uslab + i, x);
+  }
+  cost = wave_sum_dpp(cost);
+  gmax = group_max<64>(gmax);
+  const double bb = wave_sum_dpp((double)nbehind), bz = wave_sum_dpp((double)nzero);
+  if (lane == 0 && have) {
+    double* sc = SCAL_MINE(d);
+    atomic_add_f64(&sc[SC_COST], cost);
+    if (bb != 0.0) atomic_add_f64(&sc[SC_NBEHIND], bb);
+    if (bz != 0.0) atomic_add_f64(&sc[SC_ZEROZ], bz);
+    atomic_max_nonneg(&sc[SC_GINF], gmax);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_linearize_win: the lane-per-observation linearisation for ANY number of cameras.  k_linearize_flat keeps a copy of
+// U | gc of all cameras per workgroup (LDS atomics, <= 64 cameras); here the workgroup's copy holds the <= LINW_WIN
+// cameras that its four chunks touch (the host assigns the slots: the structure is static; a camera beyond the window
+// goes straight to the global slab), and the 27 values of an observation do not go through LDS atomics, where the
+// lanes of one camera collide (13 of 64 lanes on tracks of five): every lane parks its products in LDS, nine entries
+// at a time, in the row that a host-made permutation gives it (camera order: the rows of a camera are consecutive), and
+// one lane per (camera of the chunk, entry) sums that camera's rows, then adds the sum to the window.  Poses are gathered from global memory (L2 hits).
+constexpr int LINW_WIN = 32;
+template <bool ROBUST>
+__global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_win(DeviceProblem d, const double* __restrict__ poses,
+                                                                      const double* __restrict__ pts) {
+  __shared__ double sWin[LINW_WIN * 27];
+  __shared__ double sVg[LINF_WAVES][64 * LINF_VSTRIDE];
+  __shared__ double sP[LINF_WAVES][LINF_MAXLM * 3];
+  __shared__ int sGbeg[LINF_WAVES][65], sGslot[LINF_WAVES][64], sGcam[LINF_WAVES][64];
+  if (poses == nullptr) {  // solver mode
+    const LmCtrl* c = d.ctrl;
+    if (c->done || !c->need_lin) return;
+    poses = d.poses_buf[c->sel];
+    pts = d.pts_buf[c->sel];
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = __builtin_amdgcn_readfirstlane(blockIdx.x * LINF_WAVES + wave);
+  const bool have = c < d.n_lin_chunks;
+  int kb = 0, ke = 0, jb = 0, je = 0, gb = 0, ng = 0;
+  if (have) {
+    jb = d.lin_lm[c]; je = d.lin_lm[c + 1]; kb = d.lin_k[c]; ke = d.lin_k[c + 1];
+    gb = d.lin_gptr[c]; ng = d.lin_gptr[c + 1] - gb - 1;
+  }
+  for (int i = tid; i < LINW_WIN * 27; i += 64 * LINF_WAVES) sWin[i] = 0.0;
+  const int k = kb + lane;
+  const bool act = k < ke;
+  int cam = 0, fr = -1, lm = jb, tb = 0, te = 0, pos = lane;  // pos: this observation's row in camera order
+  double u = 0.0, v = 0.0, Pl[3] = {0.0, 0.0, 1.0};
+  if (act) {
+    cam = d.o_cam[k]; fr = d.o_free[k]; lm = d.o_lm[k]; u = d.o_u[k]; v = d.o_v[k];
+    pos = d.lin_perm[k];
+  }
+  if (lane < ng) {
+    sGbeg[wave][lane] = d.lin_gbeg[gb + lane]; sGslot[wave][lane] = d.lin_gslot[gb + lane]; sGcam[wave][lane] = d.lin_gcam[gb + lane];
+  }
+  if (lane == 0 && have) sGbeg[wave][ng] = d.lin_gbeg[gb + ng];  // sentinel: the number of free observations
+  const bool lm_lane = lane < je - jb;
+  if (lm_lane) {
+    tb = d.lm_ptr[jb + lane] - kb; te = d.lm_ptr[jb + lane + 1] - kb;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Pl[i] = pts[3 * (long)(jb + lane) + i];
+  }
+  double pose[7] = {0, 0, 0, 1, 0, 0, 0};
+  if (act) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) pose[i] = poses[7 * cam + i];
+  }
+  double* myP = sP[wave];
+  double* myV = sVg[wave];
+  if (lm_lane) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) myP[3 * lane + i] = Pl[i];
+  }
+  __syncthreads();  // sWin clear, myP, tables
+  const bool is_free = act && fr >= 0;
+  double cost = 0.0, gmax = 0.0;
+  int nbehind = 0, nzero = 0;
+  double vg[9], Jc[12], r[2] = {0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) vg[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
+  double zc = 1e300;
+  if (act) {
+    const double P[3] = {myP[3 * (lm - jb)], myP[3 * (lm - jb) + 1], myP[3 * (lm - jb) + 2]};
+    double Jp[6];
+    linearize_obs(d.K, pose, P, u, v, r, Jc, Jp, zc);
+    nbehind += (zc <= 0.0);
+    nzero += (zc == 0.0);
+    if (!ROBUST) {
+      cost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        double sc;
+        cost += robust_scale(d.loss, r[i], sc);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Jc[6 * i + q] *= sc;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) Jp[3 * i + q] *= sc;
+      }
+    }
+    vg[0] = Jp[0] * Jp[0] + Jp[3] * Jp[3];
+    vg[1] = Jp[0] * Jp[1] + Jp[3] * Jp[4];
+    vg[2] = Jp[0] * Jp[2] + Jp[3] * Jp[5];
+    vg[3] = Jp[1] * Jp[1] + Jp[4] * Jp[4];
+    vg[4] = Jp[1] * Jp[2] + Jp[4] * Jp[5];
+    vg[5] = Jp[2] * Jp[2] + Jp[5] * Jp[5];
+    vg[6] = Jp[0] * r[0] + Jp[3] * r[1];
+    vg[7] = Jp[1] * r[0] + Jp[4] * r[1];
+    vg[8] = Jp[2] * r[0] + Jp[5] * r[1];
+    if (!is_free) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
+    }
+    double* __restrict__ Wk = d.W + k;
+    const long n = d.n;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) Wk[(long)(3 * i + q) * n] = Jc[i] * Jp[q] + Jc[6 + i] * Jp[3 + q];
+  }
+  // V, gp of the chunk's landmarks: rows parked per observation, summed per track in track order
+#pragma unroll
+  for (int i = 0; i < 9; ++i) myV[lane * LINF_VSTRIDE + i] = vg[i];
+  myV[lane * LINF_VSTRIDE + 9] = zc;
+  // From here to the final flush a wave touches only its own rows (and the window through atomics): the LDS serves one
+  // wave's accesses in order, so a wave-level barrier (no reordering by the compiler) is all that the row exchange needs.
+  __builtin_amdgcn_wave_barrier();
+  if (lm_lane) {
+    const int jl = jb + lane;
+    double s9[9], zmn = 1e300;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s9[i] = 0.0;
+    for (int t = tb; t < te; ++t) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) s9[i] += myV[t * LINF_VSTRIDE + i];
+      zmn = fmin(zmn, myV[t * LINF_VSTRIDE + 9]);
+    }
+    d.zmin[jl] = zmn;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d.V[(long)i * d.L + jl] = s9[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d.gp[(long)i * d.L + jl] = s9[6 + i];
+    gmax = fmax(fabs(s9[6]), fmax(fabs(s9[7]), fabs(s9[8])));
+  }
+  // U | gc: 27 values per observation, nine at a time through the same rows
+  double* __restrict__ Uslab = d.Ugc_slab + (long)(blockIdx.x % d.nslab_u) * d.C * 27;
+#pragma unroll
+  for (int ph = 0; ph < 3; ++ph) {
+    __builtin_amdgcn_wave_barrier();  // the rows' previous readers are done
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+      for (int q = i; q < 6; ++q) {
+        const int e = sym6_index(i, q);
+        if (e >= 9 * ph && e < 9 * ph + 9) myV[pos * LINF_VSTRIDE + e - 9 * ph] = Jc[i] * Jc[q] + Jc[6 + i] * Jc[6 + q];
+      }
+      const int e = 21 + i;
+      if (e >= 9 * ph && e < 9 * ph + 9) myV[pos * LINF_VSTRIDE + e - 9 * ph] = Jc[i] * r[0] + Jc[6 + i] * r[1];
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int item = lane; item < ng * 9; item += 64) {
+      const int g = item / 9, q = item - 9 * g;
+      // the rows of a camera are consecutive: four independent LDS reads in flight
+      const int p1 = sGbeg[wave][g + 1];
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      for (int p = sGbeg[wave][g]; p < p1; p += 4) {
+        const double* row = myV + p * LINF_VSTRIDE + q;
+        const double a0 = row[0], a1 = p + 1 < p1 ? row[LINF_VSTRIDE] : 0.0, a2 = p + 2 < p1 ? row[2 * LINF_VSTRIDE] : 0.0,
+                     a3 = p + 3 < p1 ? row[3 * LINF_VSTRIDE] : 0.0;
+        s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+      }
+      const double sum = (s0 + s1) + (s2 + s3);
+      const int slot = sGslot[wave][g];
+      if (slot >= 0) atomic_add_f64(&sWin[slot * 27 + 9 * ph + q], sum);
+      else atomic_add_f64(&Uslab[(long)sGcam[wave][g] * 27 + 9 * ph + q], sum);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < LINW_WIN * 27; i += 64 * LINF_WAVES) {
+    const int s27 = i / 27, camw = d.lin_wincam[(long)blockIdx.x * LINW_WIN + s27];
+    const double x = sWin[i];
+    if (camw >= 0 && x != 0.0) atomic_add_f64(Uslab + (long)camw * 27 + (i - 27 * s27), x);
   }
   cost = wave_sum_dpp(cost);
   gmax = group_max<64>(gmax);

@@ -117,6 +117,7 @@ struct ba_handle {
   int g_lin = 16, g_schur = 64, lpg_lin = 1, lpg_schur = 1, lpg_back = 1;
   long contrib_rows = 0;  // rows of the contribution tiles that k_schur_staged writes per launch
   bool use_flat_backsub = true;  // BA_BACKSUB_FLAT=0: the group-per-track kernel + k_cost
+  bool lin_win = false;          // k_linearize_win takes the linearisation (chunk tables exist; BA_LIN_WIN=0: the older kernels)
   struct PosePrior {             // ba_set_pose_prior: the caller's prior, applied by every ba_set_problem until replaced
     std::vector<int> cams;
     std::vector<double> ref, H, g;
@@ -363,6 +364,12 @@ inline size_t linf_lds_bytes(int C) {
 // poses / pts == nullptr: solver mode (state and run/skip decision come from the device-side LM control)
 void launch_linearize(ba_handle* h, const double* poses, const double* pts) {
   const DeviceProblem& d = h->d;
+  if (h->lin_win) {
+    const int grid = grid_for(d.n_lin_chunks, LINF_WAVES);
+    if (d.loss.kind == LOSS_LINEAR) launch_timed(h, KT_LIN, k_linearize_win<false>, grid, 64 * LINF_WAVES, d, poses, pts);
+    else launch_timed(h, KT_LIN, k_linearize_win<true>, grid, 64 * LINF_WAVES, d, poses, pts);
+    return;
+  }
   if (h->lin_cpw > 0) {
     const int grid = grid_for(d.n_lin_chunks, LINF_WAVES);
     const size_t lds = linf_lds_bytes(d.C);
@@ -1262,6 +1269,47 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
       if (env_int("BA_LIN_FLAT", 1) != 0 && C <= LINF_MAXC) h->lin_cpw = 1;
     }
   }
+  // ---- k_linearize_win tables: per chunk the row of every observation in camera order (a permutation of the chunk's lanes)
+  // and their camera groups; per workgroup (LINF_WAVES chunks) the cameras that get a slot in its LDS copy of U | gc
+  std::vector<unsigned char> lin_perm((size_t)std::max(n, 1), 0);
+  std::vector<int> lin_gptr(1, 0), lin_gbeg, lin_gcam, lin_gslot, lin_wincam;
+  // (with <= LINF_MAXC cameras k_linearize_flat, whose LDS copy holds every camera, is the faster one: 17.5 vs 19.4 us
+  // on BASELINE configs[1]; beyond, this kernel against k_linearize<G>: 58.6 vs 70.6 us on configs[2], 604 vs 840 on [3])
+  h->lin_win = h->flat_chunks > 0 && env_int("BA_LIN_WIN", h->lin_cpw > 0 ? 0 : 1) != 0;
+  if (h->lin_win) {
+    const int nwg = (h->flat_chunks + LINF_WAVES - 1) / LINF_WAVES;
+    lin_wincam.assign((size_t)nwg * LINW_WIN, -1);
+    std::vector<int> idx;
+    for (int wg = 0; wg < nwg; ++wg) {
+      int* win = lin_wincam.data() + (size_t)wg * LINW_WIN;
+      int nwin = 0;
+      for (int c = wg * LINF_WAVES; c < std::min(h->flat_chunks, (wg + 1) * LINF_WAVES); ++c) {
+        const int kb = lin_k[c], ke = lin_k[c + 1];
+        idx.clear();
+        for (int k = kb; k < ke; ++k)
+          if (o_free[k] >= 0) idx.push_back(k);
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return o_cam[a] < o_cam[b]; });
+        {  // observations of fixed cameras take the rows after the free ones (their products are zero, nobody sums them)
+          size_t tail = idx.size();
+          for (int k = kb; k < ke; ++k)
+            if (o_free[k] < 0) lin_perm[k] = (unsigned char)tail++;
+        }
+        for (size_t p2 = 0; p2 < idx.size(); ++p2) {
+          lin_perm[idx[p2]] = (unsigned char)p2;
+          if (p2 == 0 || o_cam[idx[p2]] != o_cam[idx[p2 - 1]]) {
+            const int cam = o_cam[idx[p2]];
+            int slot = -1;
+            for (int s2 = 0; s2 < nwin; ++s2)
+              if (win[s2] == cam) slot = s2;
+            if (slot < 0 && nwin < LINW_WIN) { slot = nwin; win[nwin++] = cam; }
+            lin_gbeg.push_back((int)p2); lin_gcam.push_back(cam); lin_gslot.push_back(slot);
+          }
+        }
+        lin_gbeg.push_back((int)idx.size()); lin_gcam.push_back(-1); lin_gslot.push_back(-1);  // sentinel
+        lin_gptr.push_back((int)lin_gbeg.size());
+      }
+    }
+  }
   // ---- k_schur_staged tables: chunks (consecutive landmarks, <= SCH_CAP observations, <= SCH_MAXLM
   // landmarks), the steps at which a wave must write its accumulators out (some lane's camera pair
   // changes), the contribution rows those write-outs fill, and the inverted index S block -> rows.
@@ -1722,6 +1770,9 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
       (rc = dev_upload(h, &d.comp_local, comp_local)) || (rc = dev_upload(h, &d.comp_slot_ptr, comp_slot_ptr)) ||
       (rc = dev_upload(h, &d.comp_slots, comp_slots)) ||
       (rc = dev_upload(h, &d.lin_lm, lin_lm)) || (rc = dev_upload(h, &d.lin_k, lin_k)) ||
+      (rc = dev_upload(h, &d.lin_perm, lin_perm)) || (rc = dev_upload(h, &d.lin_gptr, lin_gptr)) ||
+      (rc = dev_upload(h, &d.lin_gbeg, lin_gbeg)) || (rc = dev_upload(h, &d.lin_gcam, lin_gcam)) ||
+      (rc = dev_upload(h, &d.lin_gslot, lin_gslot)) || (rc = dev_upload(h, &d.lin_wincam, lin_wincam)) ||
       (rc = dev_upload(h, &d.sch_lm, sch_lm)) || (rc = dev_upload(h, &d.sch_k, sch_k)) ||
       (rc = dev_upload(h, &d.sch_flush, sch_flush)) || (rc = dev_upload(h, &d.sch_blk_row, sch_blk_row)) ||
       (rc = dev_upload(h, &d.ctr_ptr, ctr_ptr)) || (rc = dev_upload(h, &d.ctr_row, ctr_row)) ||
