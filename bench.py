@@ -40,15 +40,16 @@ PROFILE_ROUND = "r02"
 
 
 def algorithmic_bytes(kernel: str, nobs: int, n_lm: int, n_cam: int, info: dict) -> float:
-    """Bytes one launch must move (DESIGN.md 'Kernels'; SURVEY.md section 8d per-unit figures)."""
-    if kernel == "k_linearize":  # read cam idx + u + v, write W; per landmark read P, write V + gp; U/gc per camera
-        return 168.0 * nobs + 120.0 * n_lm + 392.0 * n_cam
-    if kernel == "k_schur":  # read W + cam idx; per landmark V + gp; S written once
-        return 148.0 * nobs + 96.0 * n_lm
-    if kernel == "k_backsub":  # read W + cam idx; per landmark V, gp, P read, P written
+    """Bytes one launch must move (DESIGN.md 'Kernels').  W travels factored (12 doubles = 96 B per observation instead
+    of SURVEY.md section 8d's 144 B: csrc/ba_kernels.h, w_from_j), so these figures are below the survey's."""
+    if kernel == "k_linearize":  # read cam idx + u + v, write the factors of W; per landmark read P, write V + gp; U/gc per camera
+        return 120.0 * nobs + 120.0 * n_lm + 392.0 * n_cam
+    if kernel == "k_schur":  # read the factors of W + cam idx; per landmark V + gp; S written once
+        return 100.0 * nobs + 96.0 * n_lm
+    if kernel == "k_backsub":  # read the factors of W + cam idx; per landmark V, gp, P read, P written
         if info.get("linearize_flat", 0) & 2:  # k_backsub_flat: + pixels, camera index and pose id for the trial cost, zmin
-            return 172.0 * nobs + 152.0 * n_lm
-        return 148.0 * nobs + 144.0 * n_lm
+            return 124.0 * nobs + 152.0 * n_lm
+        return 100.0 * nobs + 144.0 * n_lm
     if kernel == "k_cost":
         return 24.0 * nobs + 24.0 * n_lm
     if kernel == "k_gather_S":  # every contribution row once (336 B), the U / gc slabs read and cleared, S + rhs written
@@ -57,8 +58,9 @@ def algorithmic_bytes(kernel: str, nobs: int, n_lm: int, n_cam: int, info: dict)
 
 
 def iteration_bytes(nobs: int, n_lm: int, n_cam: int) -> float:
-    """algorithmic bytes of one accepted LM iteration (before the reduced solve)."""
-    return 480.0 * nobs + 384.0 * n_lm + 900.0 * n_cam
+    """Algorithmic bytes of one accepted LM iteration (before the reduced solve): SURVEY.md section 8(d)'s 480 B per
+    observation less 3 x 48 B (W written once and read twice, factored: 96 B instead of 144 B)."""
+    return 336.0 * nobs + 384.0 * n_lm + 900.0 * n_cam
 
 
 def cpu_baseline(scene, budget_s: float):

@@ -169,6 +169,29 @@ struct DeviceProblem {
 // ordered by camera signature, so runs are long) and flushed with one fp64 atomic per entry per run.
 // Algorithmic bytes: read 20 B/obs (cam idx + u + v) + 24 B/landmark (P), write W 144 B/obs,
 // V 48 + gp 24 B/landmark, U/gc 216 B per camera run.
+// W = Jc^T Jp (6x3 per observation) is stored FACTORED: the translation half of Jc is -Jp (ba_device.h:
+// linearize_obs), so the 12 numbers [Jp (2x3) | rotation half of Jc (2x3)] are the whole of it: 96 B per observation
+// instead of 144 B, written once by the linearisation and read by the Schur and back-substitution kernels, which
+// rebuild W with 36 multiply-adds.  An observation of a fixed camera stores zeros (its W is zero).  Rows: structure
+// of arrays, d.W[r * n + k], r < W_ROWS.
+constexpr int W_ROWS = 12;
+__device__ __forceinline__ void w_pack(const double Jc[12], const double Jp[6], bool is_free, double j[W_ROWS]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    j[c] = is_free ? Jp[c] : 0.0; j[3 + c] = is_free ? Jp[3 + c] : 0.0;
+    j[6 + c] = is_free ? Jc[3 + c] : 0.0; j[9 + c] = is_free ? Jc[9 + c] : 0.0;
+  }
+}
+__device__ __forceinline__ void w_from_j(const double j[W_ROWS], double w[18]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      w[3 * i + c] = -(j[i] * j[c] + j[3 + i] * j[3 + c]);
+      w[9 + 3 * i + c] = j[6 + i] * j[c] + j[9 + i] * j[3 + c];
+    }
+}
+
 constexpr int LIN_STRIDE = 29;    // 27 values + pad (odd number of doubles: 2-way LDS write conflicts at most)
 constexpr int SCHUR_STRIDE = 37;  // 36 values + pad
 
@@ -277,14 +300,12 @@ __global__ __launch_bounds__(64, ROBUST ? 1 : LIN_WAVES) void k_linearize(Device
         g[0] += Jp[0] * r[0] + Jp[3] * r[1];
         g[1] += Jp[1] * r[0] + Jp[4] * r[1];
         g[2] += Jp[2] * r[0] + Jp[5] * r[1];
-        if (!is_free) {
+        {
+          double jw[W_ROWS];
+          w_pack(Jc, Jp, is_free, jw);
 #pragma unroll
-          for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
+          for (int i = 0; i < W_ROWS; ++i) d.W[(long)i * n + k] = jw[i];
         }
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) d.W[(long)(3 * i + c) * n + k] = Jc[i] * Jp[c] + Jc[6 + i] * Jp[3 + c];
         if (is_free) {
           cur_cam = cam;
 #pragma unroll
@@ -430,10 +451,10 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_f
     }
     double* __restrict__ Wk = d.W + k;
     const long n = d.n;
+    double jw[W_ROWS];
+    w_pack(Jc, Jp, is_free, jw);
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) Wk[(long)(3 * i + q) * n] = Jc[i] * Jp[q] + Jc[6 + i] * Jp[3 + q];
+    for (int i = 0; i < W_ROWS; ++i) Wk[(long)i * n] = jw[i];
     if (is_free) {  // U / gc of this observation into the workgroup's copy
       double* Uc = sU + cam * 27;
 #pragma unroll
@@ -587,10 +608,10 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_w
     }
     double* __restrict__ Wk = d.W + k;
     const long n = d.n;
+    double jw[W_ROWS];
+    w_pack(Jc, Jp, is_free, jw);
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) Wk[(long)(3 * i + q) * n] = Jc[i] * Jp[q] + Jc[6 + i] * Jp[3 + q];
+    for (int i = 0; i < W_ROWS; ++i) Wk[(long)i * n] = jw[i];
   }
   // V, gp of the chunk's landmarks: rows parked per observation, summed per track in track order
 #pragma unroll
@@ -1207,21 +1228,20 @@ __global__ __launch_bounds__(64, 2) void k_schur(DeviceProblem d, double lam, do
       if (act) {
         cur_a = fa; cur_b = fb; cur_sym = sym;
         const int ka = kb + a, kbb = kb + b;
-        double Y[18];
+        double Y[18], wa[18], wb[18], ja[W_ROWS], jb2[W_ROWS];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const double w[3] = {d.W[(long)(3 * i) * n + ka], d.W[(long)(3 * i + 1) * n + ka],
-                               d.W[(long)(3 * i + 2) * n + ka]};
-          sym3_mul(vi, w, &Y[3 * i]);
-        }
+        for (int i = 0; i < W_ROWS; ++i) { ja[i] = d.W[(long)i * n + ka]; jb2[i] = d.W[(long)i * n + kbb]; }
+        w_from_j(ja, wa);
+        w_from_j(jb2, wb);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sym3_mul(vi, &wa[3 * i], &Y[3 * i]);
         if (a == b) {
 #pragma unroll
           for (int i = 0; i < 6; ++i) accr[i] += Y[3 * i] * g[0] + Y[3 * i + 1] * g[1] + Y[3 * i + 2] * g[2];
         }
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-          const double w0 = d.W[(long)(3 * c) * n + kbb], w1 = d.W[(long)(3 * c + 1) * n + kbb],
-                       w2 = d.W[(long)(3 * c + 2) * n + kbb];
+          const double w0 = wb[3 * c], w1 = wb[3 * c + 1], w2 = wb[3 * c + 2];
 #pragma unroll
           for (int i = 0; i < 6; ++i) acc[6 * i + c] += Y[3 * i] * w0 + Y[3 * i + 1] * w1 + Y[3 * i + 2] * w2;
         }
@@ -1336,7 +1356,7 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
 
   // registers of the chunk in flight (raw loaded values only: arithmetic on them would make the
   // compiler wait for the loads right here)
-  double pw[18], pv[6], pg[3], plam = 0.0;
+  double pw[W_ROWS], pv[6], pg[3], plam = 0.0;
   int pfree = -1, plm = 0, pkb = 0, p_j0 = 0, p_k0 = 0, p_nobs = 0, p_nc = 0;
   auto issue = [&](int ci) {
     const int j0 = sTab[0][ci - c0], j1 = sTab[0][ci - c0 + 1], k0 = sTab[1][ci - c0], k1 = sTab[1][ci - c0 + 1];
@@ -1346,7 +1366,7 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
     p_nc = j1 - j0;
     if (lane < p_nobs) {
 #pragma unroll
-      for (int r = 0; r < 18; ++r) pw[r] = d.W[(long)r * n + k0 + lane];
+      for (int r = 0; r < W_ROWS; ++r) pw[r] = d.W[(long)r * n + k0 + lane];
       pfree = d.o_free[k0 + lane];
       plm = d.o_lm[k0 + lane];
     }
@@ -1360,7 +1380,7 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
     if (lane <= p_nc) pkb = d.lm_ptr[j0 + lane];
   };
 #pragma unroll
-  for (int r = 0; r < 18; ++r) pw[r] = 0.0;
+  for (int r = 0; r < W_ROWS; ++r) pw[r] = 0.0;
 #pragma unroll
   for (int i = 0; i < 6; ++i) pv[i] = 0.0;
 #pragma unroll
@@ -1384,19 +1404,20 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
     __syncthreads();
     if (lane < nobs) {
       const int li = plm - j0;
-      double vi[6];
+      double vi[6], w18[18];
+      w_from_j(pw, w18);  // W of this observation from its stored factors
 #pragma unroll
       for (int i = 0; i < 6; ++i) vi[i] = sVi[li * 9 + i];
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         double y[3];
-        sym3_mul(vi, &pw[3 * i], y);
+        sym3_mul(vi, &w18[3 * i], y);
         sYW[lane * SYW_STRIDE + 3 * i] = y[0];
         sYW[lane * SYW_STRIDE + 3 * i + 1] = y[1];
         sYW[lane * SYW_STRIDE + 3 * i + 2] = y[2];
       }
 #pragma unroll
-      for (int r = 0; r < 18; ++r) sYW[lane * SYW_STRIDE + 18 + r] = pw[r];
+      for (int r = 0; r < 18; ++r) sYW[lane * SYW_STRIDE + 18 + r] = w18[r];
     }
     __syncthreads();
     if (ci + 1 < c1) issue(ci + 1);  // in flight while the pairs below are multiplied
@@ -2132,10 +2153,14 @@ __global__ __launch_bounds__(256) void k_backsub(DeviceProblem d, double lam, do
       double dl[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) dl[i] = d.dc[6 * f + i];
+      double jw[W_ROWS], w18[18];
+#pragma unroll
+      for (int i = 0; i < W_ROWS; ++i) jw[i] = d.W[(long)i * n + k];
+      w_from_j(jw, w18);
 #pragma unroll
       for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) t[c] += d.W[(long)(3 * i + c) * n + k] * dl[i];
+        for (int c = 0; c < 3; ++c) t[c] += w18[3 * i + c] * dl[i];
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) t[c] = group_sum<G>(t[c]);
@@ -2253,14 +2278,14 @@ __global__ __launch_bounds__(256) void k_backsub_flat(DeviceProblem d, double la
   const bool act = k < ke;
   // round 1: everything whose address is known from the chunk bounds
   int f = -1, cam = 0, lm = jb;
-  double w[18], u = 0.0, v = 0.0;
+  double jw[W_ROWS], u = 0.0, v = 0.0;
 #pragma unroll
-  for (int i = 0; i < 18; ++i) w[i] = 0.0;
+  for (int i = 0; i < W_ROWS; ++i) jw[i] = 0.0;
   if (act) {
     f = d.o_free[k];
     lm = d.o_lm[k];
 #pragma unroll
-    for (int i = 0; i < 18; ++i) w[i] = d.W[(long)i * n + k];
+    for (int i = 0; i < W_ROWS; ++i) jw[i] = d.W[(long)i * n + k];
     if (with_cost) { cam = d.o_cam[k]; u = d.o_u[k]; v = d.o_v[k]; }
   }
   const bool lm_lane = lane < je - jb;
@@ -2291,6 +2316,8 @@ __global__ __launch_bounds__(256) void k_backsub_flat(DeviceProblem d, double la
   }
   double* myT = sT[wave];
   double* myP = sPt[wave];
+  double w[18];
+  w_from_j(jw, w);
 #pragma unroll
   for (int cc = 0; cc < 3; ++cc) {
     double t = 0.0;

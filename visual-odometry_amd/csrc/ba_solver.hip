@@ -1778,7 +1778,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
       (rc = dev_upload(h, &d.ctr_ptr, ctr_ptr)) || (rc = dev_upload(h, &d.ctr_row, ctr_row)) ||
       (rc = dev_alloc(h, &d.contrib, (size_t)contrib_rows * CTR_ROW)))
     return rc;
-  if ((rc = dev_alloc(h, &d.W, (size_t)18 * n)) || (rc = dev_alloc(h, &d.V, (size_t)6 * L)) ||
+  if ((rc = dev_alloc(h, &d.W, (size_t)W_ROWS * n)) || (rc = dev_alloc(h, &d.V, (size_t)6 * L)) ||
       (rc = dev_alloc(h, &d.gp, (size_t)3 * L)) || (rc = dev_alloc(h, &d.zmin, (size_t)L)) ||
       (rc = dev_alloc(h, &d.Ugc_part, (size_t)27 * C)) ||
       (rc = dev_alloc(h, &d.S, (size_t)36 * (nu + gap_blocks + nl))) ||
@@ -2137,9 +2137,17 @@ int ba_debug_linearization(ba_handle* h, const double* poses, const double* poin
       for (int e = 0; e < 3; ++e) gp[3 * (size_t)h->lm_internal_to_user[j] + e] = j < h->L_obs ? t[(size_t)e * L + j] : 0.0;
   }
   if (W) {
-    if ((rc = fetch(t, d.W, (size_t)18 * n))) return rc;
-    for (int k = 0; k < n; ++k)
-      for (int e = 0; e < 18; ++e) W[18 * (size_t)h->obs_src[k] + e] = t[(size_t)e * n + k];
+    if ((rc = fetch(t, d.W, (size_t)W_ROWS * n))) return rc;
+    for (int k = 0; k < n; ++k) {  // the device keeps W factored (ba_kernels.h: w_from_j): rebuild the 6 x 3 block
+      double j[W_ROWS];
+      for (int e = 0; e < W_ROWS; ++e) j[e] = t[(size_t)e * n + k];
+      double* w = W + 18 * (size_t)h->obs_src[k];
+      for (int i = 0; i < 3; ++i)
+        for (int c = 0; c < 3; ++c) {
+          w[3 * i + c] = -(j[i] * j[c] + j[3 + i] * j[3 + c]);
+          w[9 + 3 * i + c] = j[6 + i] * j[c] + j[9 + i] * j[3 + c];
+        }
+    }
   }
   if (S) {
     if ((rc = fetch(t, d.S, (size_t)36 * d.nu))) return rc;
