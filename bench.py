@@ -57,6 +57,13 @@ def algorithmic_bytes(kernel: str, nobs: int, n_lm: int, n_cam: int, info: dict)
     raise KeyError(kernel)
 
 
+def survey_bytes(kernel: str, nobs: int, n_lm: int, n_cam: int) -> float:
+    """The same launches priced with SURVEY.md section 8(d)'s per-unit figures (W as a full 6x3 block, 144 B per
+    observation): what round 1 reported, kept beside the current layout's bytes for continuity."""
+    return {"k_linearize": 168.0 * nobs + 120.0 * n_lm + 392.0 * n_cam, "k_schur": 148.0 * nobs + 96.0 * n_lm,
+            "k_backsub": 148.0 * nobs + 144.0 * n_lm}.get(kernel, 0.0)
+
+
 def iteration_bytes(nobs: int, n_lm: int, n_cam: int) -> float:
     """Algorithmic bytes of one accepted LM iteration (before the reduced solve): SURVEY.md section 8(d)'s 480 B per
     observation less 3 x 48 B (W written once and read twice, factored: 96 B instead of 144 B)."""
@@ -183,6 +190,9 @@ def run_workload(args, name, steps, warmup, dist, rank, world, local_rank, kerne
                 e.update(bound="hbm", algorithmic_bytes=b, GBps=b / (v[0] / v[1] * 1e-3) / 1e9)
                 e["frac"] = e["GBps"] / HBM_PEAK_GBS
                 e["traffic"] = traffic_db.get(k, {}).get("traffic_bytes")
+                sb = survey_bytes(k, nobs, L_local, C)
+                if sb:
+                    e["frac_survey_8d_bytes"] = sb / (v[0] / v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS
             elif k == "pcg":
                 e.update(bound="latency (one workgroup: barriers + LDS)" if info["reduced_solver"] == 1 else
                          "latency chain of block columns (banded / dense Cholesky) or fp64 MFMA (dense update)",
@@ -200,8 +210,12 @@ def run_workload(args, name, steps, warmup, dist, rank, world, local_rank, kerne
         roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic_db.get(dom, {}).get("traffic_bytes"),
                     "avg_kernel_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_launch,
+                    "frac_survey_8d_bytes": per_kernel[dom].get("frac_survey_8d_bytes"),
                     "note": "dominant (largest total time) of the HBM-streaming kernels; every kernel class of the "
-                            "solve is in per_kernel with its bound, the reduced camera solve ('pcg') included",
+                            "solve is in per_kernel with its bound, the reduced camera solve ('pcg') included.  "
+                            "Algorithmic bytes are those of the current layout (W factored: 96 B per observation, "
+                            "DESIGN.md section 5); frac_survey_8d_bytes prices the same launch with SURVEY.md 8(d)'s "
+                            "144 B, as round 1 did",
                     "whole_iteration": {"algorithmic_bytes": it_bytes, "us": it_us,
                                         "GBps": it_bytes / (it_us * 1e-6) / 1e9,
                                         "frac": it_bytes / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
