@@ -53,6 +53,28 @@ def test_window_construction():
         build_windows(kfs, map_ids, window=1)
 
 
+def test_window_prior_chart_matches_oracle():
+    """The host-side chart of the sliding-window prior (src/local_ba.py: _chart, WindowPrior.energy) against the oracle's
+    prior_chart / prior_terms: the same coordinates and the same energy, and d(retract(ref, delta)) == delta."""
+    from oracle import lm_schur_numpy as lm
+    from src.local_ba import WindowPrior, _chart
+
+    rng = np.random.default_rng(8)
+    sc = scenes.ring_scene(6, 60, 3)
+    ref = sc["poses_guess"][1:5]
+    delta = 0.2 * rng.normal(size=(4, 6))
+    poses = lm.retract(ref, delta, np.ones(4, bool))
+    np.testing.assert_allclose(_chart(poses, ref), delta, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(_chart(poses, ref), lm.prior_chart(poses, ref)[0], rtol=0, atol=1e-14)
+    A = rng.normal(size=(30, 24))
+    H, g = A.T @ A, rng.normal(size=24)
+    wp = WindowPrior(keyframes=np.arange(1, 5), ref=ref, H=H, g=g, c0=2.5)
+    full = sc["poses_guess"].copy()
+    full[1:5] = poses
+    e = lm.prior_terms(full, lm.PosePrior(cams=np.arange(1, 5), ref=ref, H=H, g=g, c0=2.5))[0]
+    assert abs(wp.energy(poses) - e) <= 1e-12 * abs(e)
+
+
 @pytest.mark.gpu
 def test_batched_windows_match_individual_solves():
     from oracle import lm_schur_numpy as lm
