@@ -118,6 +118,34 @@ def test_normal_equation_blocks_match_oracle(golden, name, lin, monkeypatch):
     close(out["dp"], dp, 1e-7)
 
 
+def test_windowed_linearisation_on_an_unstructured_scene():
+    """k_linearize_win where its LDS window overflows: 200 cameras with random visibility, so the four chunks of a
+    workgroup touch far more than 32 cameras and most camera groups go straight to the global slab.  U, g_c, V, g_p, W
+    against the numpy restatement (1e-10 of the largest entry), and the windowed kernel against the group-per-track one."""
+    import os
+    sc = scenes.ring_scene(200, 4000, 5, visibility="random")
+    C, L = 200, 4000
+    a = (sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+    outs = {}
+    for mode in ("1", "0"):
+        os.environ["BA_LIN_WIN"] = mode
+        try:
+            with _native.Solver(linear_solver=2) as s:
+                s.set_problem(C, L, *a)
+                outs[mode] = s.debug_linearization(sc["poses_guess"], sc["points_guess"], 1e-3, want_S=False)
+        finally:
+            del os.environ["BA_LIN_WIN"]
+    r, Jc, Jp = lm.linearize(sc["poses_guess"], sc["points_guess"], *a)
+    free = np.ones(C, bool)
+    free[0] = False
+    Jc = Jc * free[sc["obs_cam"]][:, None, None]
+    U, V, W, gc, gp, _ = lm.normal_blocks(r, Jc, Jp, sc["obs_cam"], sc["obs_pt"], C, L)
+    for mode, out in outs.items():
+        for k, ref in (("U", U), ("V", V), ("W", W), ("gc", gc), ("gp", gp)):
+            np.testing.assert_allclose(out[k], ref, rtol=0, atol=1e-10 * np.abs(ref).max(), err_msg=f"{k} (BA_LIN_WIN={mode})")
+    np.testing.assert_allclose(outs["1"]["dc"], outs["0"]["dc"], rtol=0, atol=1e-9 * np.abs(outs["0"]["dc"]).max())
+
+
 @pytest.mark.parametrize("name", ["noisy_10x300", "ring_50x2000"])
 def test_converged_cost_matches_reference(golden, name):
     """north_star: converged cost within 1e-6 relative of the reference's scipy path: one-sided
