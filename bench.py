@@ -42,11 +42,14 @@ PROFILE_ROUND = "r02"
 def algorithmic_bytes(kernel: str, nobs: int, n_lm: int, n_cam: int, info: dict) -> float:
     """Bytes one launch must move (DESIGN.md 'Kernels').  W travels factored (12 doubles = 96 B per observation instead
     of SURVEY.md section 8d's 144 B: csrc/ba_kernels.h, w_from_j), so these figures are below the survey's."""
+    mf = info.get("linearize_flat", 0) & 4  # matrix-free path (>= 2 M observations): W is rebuilt, never stored
     if kernel == "k_linearize":  # read cam idx + u + v, write the factors of W; per landmark read P, write V + gp; U/gc per camera
-        return 120.0 * nobs + 120.0 * n_lm + 392.0 * n_cam
-    if kernel == "k_schur":  # read the factors of W + cam idx; per landmark V + gp; S written once
-        return 100.0 * nobs + 96.0 * n_lm
+        return (24.0 if mf else 120.0) * nobs + 120.0 * n_lm + 392.0 * n_cam
+    if kernel == "k_schur":  # read the factors of W + cam idx (mf: the record, 28 B); per landmark V + gp (mf: + P); S written once
+        return (28.0 * nobs + 120.0 * n_lm) if mf else (100.0 * nobs + 96.0 * n_lm)
     if kernel == "k_backsub":  # read the factors of W + cam idx; per landmark V, gp, P read, P written
+        if mf:
+            return 28.0 * nobs + 152.0 * n_lm
         if info.get("linearize_flat", 0) & 2:  # k_backsub_flat: + pixels, camera index and pose id for the trial cost, zmin
             return 124.0 * nobs + 152.0 * n_lm
         return 100.0 * nobs + 144.0 * n_lm
@@ -64,9 +67,12 @@ def survey_bytes(kernel: str, nobs: int, n_lm: int, n_cam: int) -> float:
             "k_backsub": 148.0 * nobs + 144.0 * n_lm}.get(kernel, 0.0)
 
 
-def iteration_bytes(nobs: int, n_lm: int, n_cam: int) -> float:
+def iteration_bytes(nobs: int, n_lm: int, n_cam: int, info: dict = None) -> float:
     """Algorithmic bytes of one accepted LM iteration (before the reduced solve): SURVEY.md section 8(d)'s 480 B per
-    observation less 3 x 48 B (W written once and read twice, factored: 96 B instead of 144 B)."""
+    observation less 3 x 48 B (W written once and read twice, factored: 96 B instead of 144 B); on the matrix-free path
+    the observation records only (24 + 28 + 28 B)."""
+    if info and info.get("linearize_flat", 0) & 4:
+        return 80.0 * nobs + 432.0 * n_lm + 900.0 * n_cam
     return 336.0 * nobs + 384.0 * n_lm + 900.0 * n_cam
 
 
@@ -205,7 +211,7 @@ def run_workload(args, name, steps, warmup, dist, rank, world, local_rank, kerne
         avg_ms = stream[dom][0] / stream[dom][1]
         bytes_launch = algorithmic_bytes(dom, nobs, L_local, C, info)
         ach = bytes_launch / (avg_ms * 1e-3) / 1e9
-        it_bytes = iteration_bytes(nobs, L_local, C)
+        it_bytes = iteration_bytes(nobs, L_local, C, info)
         it_us = 1e3 * rep["solve_ms"] / max(1, rep["iterations"])
         roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic_db.get(dom, {}).get("traffic_bytes"),

@@ -314,7 +314,8 @@ int ba_reduced_solver(const ba_handle* h, int32_t* kind);
  * gather reads per launch (0 on the atomics path), 2 Schur chunks, 3 copies of the U / gc slabs, 4 reduced solver (as
  * ba_reduced_solver), 5 / 6 half-bandwidth and arrow size of the banded solver (level 2 when segmented; cyclic reduction:
  * cameras per super-block and levels), 7 segments of the two-level banded solver (0: one level; cyclic reduction:
- * super-blocks), 8 free cameras, 9 observed landmarks, 10 1 if k_linearize_flat is used,
+ * super-blocks), 8 free cameras, 9 observed landmarks, 10 kernel choices as bits (1: k_linearize_flat, 2: k_backsub_flat,
+ * 4: matrix-free path: no stored W, the Schur and back-substitution kernels rebuild it; 8: k_linearize_win),
  * 11 connected components of the camera graph. */
 #define BA_INFO_COUNT 12
 int ba_problem_info(const ba_handle* h, int64_t* info);

@@ -81,18 +81,20 @@ def test_jacobian_blocks_vs_finite_differences(golden, name):
             assert np.abs(Jp[sel][:, :, k] - fd[sel]).max() <= 1e-6 * np.abs(fd[sel]).max()
 
 
-@pytest.mark.parametrize("lin", ["default", "window", "group"])
+@pytest.mark.parametrize("lin", ["default", "window", "group", "matrix_free"])
 @pytest.mark.parametrize("name", ["test_scene_convergence", "noisy_10x300"])
 def test_normal_equation_blocks_match_oracle(golden, name, lin, monkeypatch):
     """U, V, W, gradients, Schur complement S, reduced rhs and the LM step against the numpy
     restatement; fp64 sums in different orders: 1e-10 relative to the largest entry.  With each of the three
     linearisation kernels: the default for few cameras (k_linearize_flat), k_linearize_win (what problems with more
-    than 64 cameras take) and the group-per-track k_linearize<G> (tracks longer than 32)."""
+    than 64 cameras take) and the group-per-track k_linearize<G> (tracks longer than 32); and on the matrix-free path."""
     if lin == "window":
         monkeypatch.setenv("BA_LIN_WIN", "1")
     elif lin == "group":
         monkeypatch.setenv("BA_LIN_WIN", "0")
         monkeypatch.setenv("BA_LIN_FLAT", "0")
+    elif lin == "matrix_free":  # no stored W: the Schur and back-substitution kernels rebuild it (the default from 2 M observations)
+        monkeypatch.setenv("BA_MATRIX_FREE", "1")
     g = golden(name)
     n_poses, poses, pts = _state(g)
     C, L = n_poses + 1, len(pts)

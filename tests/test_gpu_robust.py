@@ -88,10 +88,13 @@ def test_distorted_converged_cost_matches_reference(golden):
     assert abs(rep["cost"] - pol) <= 1e-6 * pol, (rep["cost"], pol)
 
 
+@pytest.mark.parametrize("matrix_free", [False, True], ids=["stored_w", "matrix_free"])
 @pytest.mark.parametrize("loss", ROBUST)
-def test_robust_blocks_match_oracle(golden, loss):
+def test_robust_blocks_match_oracle(golden, loss, matrix_free, monkeypatch):
     """Robust cost at x0 vs the value recorded from the reference's residuals (1e-12 relative); the
-    re-weighted U, V, W, gradients, S, rhs and LM step vs the numpy restatement."""
+    re-weighted U, V, W, gradients, S, rhs and LM step vs the numpy restatement; with W stored (factored) and with W
+    rebuilt, re-weighting included, by the Schur and back-substitution kernels (the path of problems >= 2 M observations)."""
+    monkeypatch.setenv("BA_MATRIX_FREE", "1" if matrix_free else "0")
     g = golden("outliers_10x300")
     n_poses, poses, pts = _state(g)
     C, L = n_poses + 1, len(pts)

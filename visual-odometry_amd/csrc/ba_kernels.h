@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64, ROBUST ? 1 : LIN_WAVES) void k_linearize(Device
         g[0] += Jp[0] * r[0] + Jp[3] * r[1];
         g[1] += Jp[1] * r[0] + Jp[4] * r[1];
         g[2] += Jp[2] * r[0] + Jp[5] * r[1];
-        {
+        if (d.W) {  // (no buffer: the consumers rebuild W themselves)
           double jw[W_ROWS];
           w_pack(Jc, Jp, is_free, jw);
 #pragma unroll
@@ -449,12 +449,14 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_f
 #pragma unroll
       for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
     }
-    double* __restrict__ Wk = d.W + k;
-    const long n = d.n;
-    double jw[W_ROWS];
-    w_pack(Jc, Jp, is_free, jw);
+    if (d.W) {  // (no buffer: the consumers rebuild W themselves)
+      double* __restrict__ Wk = d.W + k;
+      const long n = d.n;
+      double jw[W_ROWS];
+      w_pack(Jc, Jp, is_free, jw);
 #pragma unroll
-    for (int i = 0; i < W_ROWS; ++i) Wk[(long)i * n] = jw[i];
+      for (int i = 0; i < W_ROWS; ++i) Wk[(long)i * n] = jw[i];
+    }
     if (is_free) {  // U / gc of this observation into the workgroup's copy
       double* Uc = sU + cam * 27;
 #pragma unroll
@@ -606,12 +608,14 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_w
 #pragma unroll
       for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
     }
-    double* __restrict__ Wk = d.W + k;
-    const long n = d.n;
-    double jw[W_ROWS];
-    w_pack(Jc, Jp, is_free, jw);
+    if (d.W) {  // (no buffer: the consumers rebuild W themselves)
+      double* __restrict__ Wk = d.W + k;
+      const long n = d.n;
+      double jw[W_ROWS];
+      w_pack(Jc, Jp, is_free, jw);
 #pragma unroll
-    for (int i = 0; i < W_ROWS; ++i) Wk[(long)i * n] = jw[i];
+      for (int i = 0; i < W_ROWS; ++i) Wk[(long)i * n] = jw[i];
+    }
   }
   // V, gp of the chunk's landmarks: rows parked per observation, summed per track in track order
 #pragma unroll
@@ -1042,6 +1046,29 @@ __global__ __launch_bounds__(256) void k_export_jac(DeviceProblem d,
   }
 }
 
+// The factors of W of every observation at (poses, pts), in the layout of d.W: what the debug export reads when the
+// solver keeps no W buffer (matrix-free path).
+__global__ __launch_bounds__(256) void k_export_w(DeviceProblem d, const double* __restrict__ poses,
+                                                  const double* __restrict__ pts, double* __restrict__ Wout) {
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < d.n; k += (long)gridDim.x * blockDim.x) {
+    const int cam = d.o_cam[k];
+    const long j = d.o_lm[k];
+    const double P[3] = {pts[3 * j], pts[3 * j + 1], pts[3 * j + 2]};
+    double r[2], Jc[12], Jp[6], zc, jw[W_ROWS];
+    linearize_obs(d.K, poses + 7 * cam, P, d.o_u[k], d.o_v[k], r, Jc, Jp, zc);
+    if (d.loss.kind != LOSS_LINEAR) {
+      for (int i = 0; i < 2; ++i) {
+        double sc;
+        (void)robust_scale(d.loss, r[i], sc);
+        for (int q = 0; q < 6; ++q) Jc[6 * i + q] *= sc;
+        for (int q = 0; q < 3; ++q) Jp[3 * i + q] *= sc;
+      }
+    }
+    w_pack(Jc, Jp, d.o_free[k] >= 0, jw);
+    for (int i = 0; i < W_ROWS; ++i) Wout[(long)i * d.n + k] = jw[i];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_reduce_U: Ugc[c][e] = sum over slabs; inf-norm of the camera gradient.  One thread per entry.
 __global__ __launch_bounds__(256) void k_reduce_U(DeviceProblem d, int solver_mode) {
@@ -1282,14 +1309,24 @@ constexpr int SYW_STRIDE = 38;  // Y[18] | W[18] | 2 pad doubles (rows stay 16-b
 constexpr int CTR_ROW = 42;     // doubles per contribution row: 6x6 block | 6 reduced-rhs entries
 constexpr int FLUSH_NV = 7, FLUSH_STRIDE = FLUSH_NV;  // columns per flush pass (divides CTR_ROW; odd: no LDS padding needed)
 
-template <int G>
-__global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double lam, double min_diag, int cpb) {
+// MF ("matrix free"): W is not read from memory but rebuilt from the observation record, the pose and the point
+// (linearize_obs: the same arithmetic as the linearisation kernels), with the loads in two stages so that none is
+// waited for: the records of chunk ci + 2 and the poses (gathered by the camera index of the records loaded one stage
+// earlier), V, gp and points of chunk ci + 1 are in flight while the pairs of chunk ci are multiplied.
+template <int G, bool MF>
+__global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double lam, double min_diag, int cpb,
+                                                        const double* __restrict__ poses, const double* __restrict__ pts) {
   __shared__ double stage[64 * FLUSH_STRIDE];
   __shared__ __align__(16) double sYW[SCH_CAP * SYW_STRIDE];
   __shared__ double sVi[SCH_MAXLM * 9];  // Vd^-1 (6) | gp (3) per landmark of the chunk
   __shared__ int sFree[SCH_CAP];
   __shared__ int sKb[SCH_MAXLM + 1];
   __shared__ int sTab[3][SCH_MAXCPB + 1];  // this block's chunks: first landmark | first observation | flush bits
+  __shared__ double sPts[MF ? SCH_MAXLM * 3 : 1];
+  if (MF && lam < 0.0) {
+    poses = d.poses_buf[d.ctrl->sel];
+    pts = d.pts_buf[d.ctrl->sel];
+  }
   const bool per_comp = lam < 0.0 && d.clm.lam_lm != nullptr;  // solver mode with a damping per component
   if (lam < 0.0) {  // solver mode
     if (d.ctrl->done) return;
@@ -1356,8 +1393,18 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
 
   // registers of the chunk in flight (raw loaded values only: arithmetic on them would make the
   // compiler wait for the loads right here)
-  double pw[W_ROWS], pv[6], pg[3], plam = 0.0;
+  double pw[MF ? 7 : W_ROWS], pv[6], pg[3], plam = 0.0;  // MF: pw is the pose of the observation's camera
+  double pP[3] = {0.0, 0.0, 1.0}, pu = 0.0, pvv = 0.0;   // MF: the landmark's point (landmark lanes), the pixel
+  int a_cam = 0, a_free = -1, a_lm = 0;                  // MF, stage A: the record of chunk ci + 2
+  double a_u = 0.0, a_v = 0.0;
   int pfree = -1, plm = 0, pkb = 0, p_j0 = 0, p_k0 = 0, p_nobs = 0, p_nc = 0;
+  auto issue_records = [&](int ci) {  // MF stage A
+    const int k0 = sTab[1][ci - c0], k1 = sTab[1][ci - c0 + 1];
+    if (lane < k1 - k0) {
+      a_cam = d.o_cam[k0 + lane]; a_free = d.o_free[k0 + lane]; a_lm = d.o_lm[k0 + lane];
+      a_u = d.o_u[k0 + lane]; a_v = d.o_v[k0 + lane];
+    }
+  };
   auto issue = [&](int ci) {
     const int j0 = sTab[0][ci - c0], j1 = sTab[0][ci - c0 + 1], k0 = sTab[1][ci - c0], k1 = sTab[1][ci - c0 + 1];
     p_j0 = j0;
@@ -1365,12 +1412,22 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
     p_nobs = k1 - k0;
     p_nc = j1 - j0;
     if (lane < p_nobs) {
+      if constexpr (MF) {  // stage B: the records of this chunk are in the stage-A registers
 #pragma unroll
-      for (int r = 0; r < W_ROWS; ++r) pw[r] = d.W[(long)r * n + k0 + lane];
-      pfree = d.o_free[k0 + lane];
-      plm = d.o_lm[k0 + lane];
+        for (int r = 0; r < 7; ++r) pw[r] = poses[7 * a_cam + r];
+        pfree = a_free; plm = a_lm; pu = a_u; pvv = a_v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < W_ROWS; ++r) pw[r] = d.W[(long)r * n + k0 + lane];
+        pfree = d.o_free[k0 + lane];
+        plm = d.o_lm[k0 + lane];
+      }
     }
     if (lane < p_nc) {
+      if constexpr (MF) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pP[i] = pts[3 * (long)(j0 + lane) + i];
+      }
 #pragma unroll
       for (int i = 0; i < 6; ++i) pv[i] = d.V[(long)i * L + j0 + lane];
 #pragma unroll
@@ -1380,12 +1437,16 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
     if (lane <= p_nc) pkb = d.lm_ptr[j0 + lane];
   };
 #pragma unroll
-  for (int r = 0; r < W_ROWS; ++r) pw[r] = 0.0;
+  for (int r = 0; r < (MF ? 7 : W_ROWS); ++r) pw[r] = MF && r == 3 ? 1.0 : 0.0;
 #pragma unroll
   for (int i = 0; i < 6; ++i) pv[i] = 0.0;
 #pragma unroll
   for (int i = 0; i < 3; ++i) pg[i] = 0.0;
+  if constexpr (MF) issue_records(c0);
   issue(c0);
+  if constexpr (MF) {
+    if (c0 + 1 < c1) issue_records(c0 + 1);
+  }
   for (int ci = c0; ci < c1; ++ci) {
     const int nobs = p_nobs, nc = p_nc, j0 = p_j0, k0 = p_k0;
     const unsigned fbits = (unsigned)sTab[2][ci - c0];
@@ -1398,6 +1459,10 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
       for (int i = 0; i < 6; ++i) sVi[lane * 9 + i] = vi[i];
 #pragma unroll
       for (int i = 0; i < 3; ++i) sVi[lane * 9 + 6 + i] = pg[i];
+      if constexpr (MF) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sPts[lane * 3 + i] = pP[i];
+      }
     }
     if (lane <= nc) sKb[lane] = pkb - k0;
     if (lane < nobs) sFree[lane] = pfree;
@@ -1405,7 +1470,26 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
     if (lane < nobs) {
       const int li = plm - j0;
       double vi[6], w18[18];
-      w_from_j(pw, w18);  // W of this observation from its stored factors
+      if constexpr (MF) {
+        const double P[3] = {sPts[li * 3], sPts[li * 3 + 1], sPts[li * 3 + 2]};
+        double r[2], Jc[12], Jp[6], zc, jw[W_ROWS];
+        linearize_obs(d.K, pw, P, pu, pvv, r, Jc, Jp, zc);
+        if (d.loss.kind != LOSS_LINEAR) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            double sc;
+            (void)robust_scale(d.loss, r[i], sc);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) Jc[6 * i + q] *= sc;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) Jp[3 * i + q] *= sc;
+          }
+        }
+        w_pack(Jc, Jp, pfree >= 0, jw);
+        w_from_j(jw, w18);
+      } else {
+        w_from_j(pw, w18);  // W of this observation from its stored factors
+      }
 #pragma unroll
       for (int i = 0; i < 6; ++i) vi[i] = sVi[li * 9 + i];
 #pragma unroll
@@ -1421,6 +1505,9 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
     }
     __syncthreads();
     if (ci + 1 < c1) issue(ci + 1);  // in flight while the pairs below are multiplied
+    if constexpr (MF) {
+      if (ci + 2 < c1) issue_records(ci + 2);
+    }
     for (int l0 = 0, step = 0; l0 < nc; l0 += GPW, ++step) {
       if ((fbits >> step) & 1u) flush();
       const int li = l0 + grp;
@@ -2277,6 +2364,7 @@ __global__ __launch_bounds__(256) void k_backsub_flat(DeviceProblem d, double la
   const int k = kb + lane;
   const bool act = k < ke;
   // round 1: everything whose address is known from the chunk bounds
+  const bool mf = d.W == nullptr;  // matrix free: W is rebuilt from the record, the pose and the point (no stored factors)
   int f = -1, cam = 0, lm = jb;
   double jw[W_ROWS], u = 0.0, v = 0.0;
 #pragma unroll
@@ -2284,9 +2372,11 @@ __global__ __launch_bounds__(256) void k_backsub_flat(DeviceProblem d, double la
   if (act) {
     f = d.o_free[k];
     lm = d.o_lm[k];
+    if (!mf) {
 #pragma unroll
-    for (int i = 0; i < W_ROWS; ++i) jw[i] = d.W[(long)i * n + k];
-    if (with_cost) { cam = d.o_cam[k]; u = d.o_u[k]; v = d.o_v[k]; }
+      for (int i = 0; i < W_ROWS; ++i) jw[i] = d.W[(long)i * n + k];
+    }
+    if (with_cost || mf) { cam = d.o_cam[k]; u = d.o_u[k]; v = d.o_v[k]; }
   }
   const bool lm_lane = lane < je - jb;
   const long j = jb + lane;
@@ -2310,12 +2400,34 @@ __global__ __launch_bounds__(256) void k_backsub_flat(DeviceProblem d, double la
 #pragma unroll
     for (int i = 0; i < 6; ++i) dl[i] = d.dc[6 * f + i];
   }
-  if (act && with_cost) {
+  if (act && (with_cost || mf)) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) ps[i] = poses[7 * cam + i];
   }
   double* myT = sT[wave];
   double* myP = sPt[wave];
+  if (mf) {  // the current points to the observation lanes (the same rows take the trial points later, after a barrier)
+    if (lm_lane) { myP[3 * lane] = P[0]; myP[3 * lane + 1] = P[1]; myP[3 * lane + 2] = P[2]; }
+    __syncthreads();
+    if (act) {
+      const int li = lm - jb;
+      const double Pc[3] = {myP[3 * li], myP[3 * li + 1], myP[3 * li + 2]};
+      double r[2], Jc[12], Jp[6], zc;
+      linearize_obs(d.K, ps, Pc, u, v, r, Jc, Jp, zc);
+      if (ROBUST) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          double sc;
+          (void)robust_scale(d.loss, r[i], sc);
+#pragma unroll
+          for (int q = 0; q < 6; ++q) Jc[6 * i + q] *= sc;
+#pragma unroll
+          for (int q = 0; q < 3; ++q) Jp[3 * i + q] *= sc;
+        }
+      }
+      w_pack(Jc, Jp, f >= 0, jw);
+    }
+  }
   double w[18];
   w_from_j(jw, w);
 #pragma unroll

@@ -117,6 +117,7 @@ struct ba_handle {
   int g_lin = 16, g_schur = 64, lpg_lin = 1, lpg_schur = 1, lpg_back = 1;
   long contrib_rows = 0;  // rows of the contribution tiles that k_schur_staged writes per launch
   bool use_flat_backsub = true;  // BA_BACKSUB_FLAT=0: the group-per-track kernel + k_cost
+  bool matrix_free = false;      // no W buffer: k_schur_staged<MF> and k_backsub_flat rebuild W (BA_MATRIX_FREE=0: stored factors)
   bool lin_win = false;          // k_linearize_win takes the linearisation (chunk tables exist; BA_LIN_WIN=0: the older kernels)
   struct PosePrior {             // ba_set_pose_prior: the caller's prior, applied by every ba_set_problem until replaced
     std::vector<int> cams;
@@ -432,11 +433,23 @@ void launch_schur(ba_handle* h, double lam) {
   const double md = h->opt.min_diag;
   if (h->schur_cpb > 0) {
     const int cpb = h->schur_cpb, grid = grid_for(d.n_chunks, cpb);
-    switch (G) {
-      case 8: launch_timed(h, KT_SCHUR, k_schur_staged<8>, grid, 64, d, lam, md, cpb); break;
-      case 16: launch_timed(h, KT_SCHUR, k_schur_staged<16>, grid, 64, d, lam, md, cpb); break;
-      case 32: launch_timed(h, KT_SCHUR, k_schur_staged<32>, grid, 64, d, lam, md, cpb); break;
-      default: launch_timed(h, KT_SCHUR, k_schur_staged<64>, grid, 64, d, lam, md, cpb); break;
+    // explicit mode (lam >= 0): the point that ba_debug_linearization staged in buffer 0
+    const double* P = lam < 0.0 ? nullptr : (const double*)d.poses_buf[0];
+    const double* X = lam < 0.0 ? nullptr : (const double*)d.pts_buf[0];
+    if (h->matrix_free) {
+      switch (G) {
+        case 8: launch_timed(h, KT_SCHUR, k_schur_staged<8, true>, grid, 64, d, lam, md, cpb, P, X); break;
+        case 16: launch_timed(h, KT_SCHUR, k_schur_staged<16, true>, grid, 64, d, lam, md, cpb, P, X); break;
+        case 32: launch_timed(h, KT_SCHUR, k_schur_staged<32, true>, grid, 64, d, lam, md, cpb, P, X); break;
+        default: launch_timed(h, KT_SCHUR, k_schur_staged<64, true>, grid, 64, d, lam, md, cpb, P, X); break;
+      }
+    } else {
+      switch (G) {
+        case 8: launch_timed(h, KT_SCHUR, k_schur_staged<8, false>, grid, 64, d, lam, md, cpb, P, X); break;
+        case 16: launch_timed(h, KT_SCHUR, k_schur_staged<16, false>, grid, 64, d, lam, md, cpb, P, X); break;
+        case 32: launch_timed(h, KT_SCHUR, k_schur_staged<32, false>, grid, 64, d, lam, md, cpb, P, X); break;
+        default: launch_timed(h, KT_SCHUR, k_schur_staged<64, false>, grid, 64, d, lam, md, cpb, P, X); break;
+      }
     }
     return;
   }
@@ -943,7 +956,7 @@ int ba_problem_info(const ba_handle* h, int64_t* info) {
                                     h->bcr_solve ? h->bcr_plan.m / 6 : h->banded_solve ? h->bshape.bw : 0,
                                     h->bcr_solve ? h->bcr_plan.n_levels : h->banded_solve ? h->bshape.na : 0,
                                     h->bcr_solve ? h->bcr_plan.N : h->bseg_P,
-                                    h->Cf, h->L_obs, (h->lin_cpw > 0 ? 1 : 0) | (h->flat_chunks > 0 && h->use_flat_backsub ? 2 : 0),
+                                    h->Cf, h->L_obs, (h->lin_cpw > 0 ? 1 : 0) | (h->flat_chunks > 0 && h->use_flat_backsub ? 2 : 0) | (h->matrix_free ? 4 : 0) | (h->lin_win ? 8 : 0),
                                     h->d.n_comp};
   for (int i = 0; i < BA_INFO_COUNT; ++i) info[i] = v[i];
   return BA_OK;
@@ -1402,6 +1415,13 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
       }
     }
   }
+  // W is not stored when both of its readers can rebuild it (the staged Schur kernel and the flat back-substitution)
+  // and the problem is large enough for the traffic to matter: measured per LM iteration, stored / rebuilt: config 2
+  // (0.2 M observations) 135 / 137 us, config 3 (1 M) 395 / 398 us, config 4 (10 M) 1.89 / 1.76 ms (the linearisation
+  // loses its 96 B per observation of stores, the back-substitution its loads; the Schur kernel, which is not bound by
+  // memory, pays 8-14 % for the arithmetic).  Rebuilding also frees 96 B per observation (0.96 GB at config 4).
+  h->matrix_free = h->schur_cpb > 0 && h->flat_chunks > 0 && h->use_flat_backsub &&
+                   env_int("BA_MATRIX_FREE", n >= 2000000 ? 1 : 0) != 0;
   // privatised slabs: as many copies as fit a fixed budget, so that few atomics share an address
   {
     const size_t u_bytes = (size_t)C * 27 * sizeof(double);
@@ -1778,7 +1798,9 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
       (rc = dev_upload(h, &d.ctr_ptr, ctr_ptr)) || (rc = dev_upload(h, &d.ctr_row, ctr_row)) ||
       (rc = dev_alloc(h, &d.contrib, (size_t)contrib_rows * CTR_ROW)))
     return rc;
-  if ((rc = dev_alloc(h, &d.W, (size_t)W_ROWS * n)) || (rc = dev_alloc(h, &d.V, (size_t)6 * L)) ||
+  d.W = nullptr;
+  if (!h->matrix_free && (rc = dev_alloc(h, &d.W, (size_t)W_ROWS * n))) return rc;
+  if ((rc = dev_alloc(h, &d.V, (size_t)6 * L)) ||
       (rc = dev_alloc(h, &d.gp, (size_t)3 * L)) || (rc = dev_alloc(h, &d.zmin, (size_t)L)) ||
       (rc = dev_alloc(h, &d.Ugc_part, (size_t)27 * C)) ||
       (rc = dev_alloc(h, &d.S, (size_t)36 * (nu + gap_blocks + nl))) ||
@@ -2137,7 +2159,16 @@ int ba_debug_linearization(ba_handle* h, const double* poses, const double* poin
       for (int e = 0; e < 3; ++e) gp[3 * (size_t)h->lm_internal_to_user[j] + e] = j < h->L_obs ? t[(size_t)e * L + j] : 0.0;
   }
   if (W) {
-    if ((rc = fetch(t, d.W, (size_t)W_ROWS * n))) return rc;
+    DevTmp t_w;
+    const double* w_src = d.W;
+    if (!w_src) {  // matrix-free path: no stored factors, compute them for the export
+      HIP_TRY(h, hipMalloc(&t_w.p, (size_t)W_ROWS * n * sizeof(double)));
+      k_export_w<<<std::min(grid_for(n), 4096), 256, 0, h->stream>>>(d, (const double*)P0, (const double*)X0, static_cast<double*>(t_w.p));
+      note_launch(h);
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+      w_src = static_cast<const double*>(t_w.p);
+    }
+    if ((rc = fetch(t, w_src, (size_t)W_ROWS * n))) return rc;
     for (int k = 0; k < n; ++k) {  // the device keeps W factored (ba_kernels.h: w_from_j): rebuild the 6 x 3 block
       double j[W_ROWS];
       for (int e = 0; e < W_ROWS; ++e) j[e] = t[(size_t)e * n + k];
