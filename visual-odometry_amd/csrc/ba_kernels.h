@@ -514,7 +514,10 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_f
 // lanes of one camera collide (13 of 64 lanes on tracks of five): every lane parks its products in LDS, nine entries
 // at a time, in the row that a host-made permutation gives it (camera order: the rows of a camera are consecutive), and
 // one lane per (camera of the chunk, entry) sums that camera's rows, then adds the sum to the window.  Poses are gathered from global memory (L2 hits).
-constexpr int LINW_WIN = 32;
+#ifndef LINW_WIN_SLOTS
+#define LINW_WIN_SLOTS 16  // 32 KB of LDS per workgroup: five workgroups per CU (32 slots: four; 49 vs 47.5 us at config 3, 391 vs 367 at config 4)
+#endif
+constexpr int LINW_WIN = LINW_WIN_SLOTS;
 template <bool ROBUST>
 __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_win(DeviceProblem d, const double* __restrict__ poses,
                                                                       const double* __restrict__ pts) {
