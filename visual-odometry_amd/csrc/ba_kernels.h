@@ -2585,6 +2585,9 @@ __global__ __launch_bounds__(256) void k_lm_decide(DeviceProblem d, const double
   }
   __shared__ double part[8][SC_COUNT];
   __shared__ double s[SC_COUNT];
+  // the control head and the solver's iteration count are requested with the statistics: one round trip, not two
+  const LmHead h_in = *static_cast<const LmHead*>(c);
+  const double pcg_in = d.scal[SC_PCGIT];
   const int t = threadIdx.x, i = t & (SC_COUNT - 1), g = t / SC_COUNT;  // 8 groups x 32 slots
   {
     const bool is_max = (i == SC_GINF || i == SC_GINF_C);
@@ -2622,8 +2625,8 @@ __global__ __launch_bounds__(256) void k_lm_decide(DeviceProblem d, const double
   __syncthreads();
   if (t != 0) return;
   // one snapshot of the control head (wide loads, one round trip), written back once at the end
-  LmHead h = *static_cast<const LmHead*>(c);
-  const int pcg_it = (int)d.scal[SC_PCGIT];
+  LmHead h = h_in;
+  const int pcg_it = (int)pcg_in;
   const int it = ++h.it;
   bool early = false;
   if (h.need_lin) {
