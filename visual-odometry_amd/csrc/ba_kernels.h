@@ -2431,14 +2431,11 @@ __global__ __launch_bounds__(256) void k_backsub_flat(DeviceProblem d, double la
       w_pack(Jc, Jp, f >= 0, jw);
     }
   }
-  double w[18];
-  w_from_j(jw, w);
+  {  // W^T dl = Jp^T (Jc dl), Jc = [-Jp | Jr]: the 6x3 block is never formed
+    const double a0 = -(jw[0] * dl[0] + jw[1] * dl[1] + jw[2] * dl[2]) + jw[6] * dl[3] + jw[7] * dl[4] + jw[8] * dl[5];
+    const double a1 = -(jw[3] * dl[0] + jw[4] * dl[1] + jw[5] * dl[2]) + jw[9] * dl[3] + jw[10] * dl[4] + jw[11] * dl[5];
 #pragma unroll
-  for (int cc = 0; cc < 3; ++cc) {
-    double t = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) t += w[3 * i + cc] * dl[i];
-    myT[3 * lane + cc] = t;
+    for (int cc = 0; cc < 3; ++cc) myT[3 * lane + cc] = jw[cc] * a0 + jw[3 + cc] * a1;
   }
   __syncthreads();  // (each wave only reads its own rows; every wave of the block reaches the barriers)
   double gd = 0.0, dhd = 0.0, dn = 0.0, xn = 0.0;
