@@ -1267,13 +1267,14 @@ __global__ __launch_bounds__(64, 2) void k_schur(DeviceProblem d, double lam, do
         for (int i = 0; i < 6; ++i) sym3_mul(vi, &wa[3 * i], &Y[3 * i]);
         if (a == b) {
 #pragma unroll
-          for (int i = 0; i < 6; ++i) accr[i] += Y[3 * i] * g[0] + Y[3 * i + 1] * g[1] + Y[3 * i + 2] * g[2];
+          for (int i = 0; i < 6; ++i) accr[i] = fma(Y[3 * i + 2], g[2], fma(Y[3 * i + 1], g[1], fma(Y[3 * i], g[0], accr[i])));
         }
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
           const double w0 = wb[3 * c], w1 = wb[3 * c + 1], w2 = wb[3 * c + 2];
 #pragma unroll
-          for (int i = 0; i < 6; ++i) acc[6 * i + c] += Y[3 * i] * w0 + Y[3 * i + 1] * w1 + Y[3 * i + 2] * w2;
+          for (int i = 0; i < 6; ++i)  // three chained FMAs into the accumulator (a sum formed first costs a fourth instruction)
+            acc[6 * i + c] = fma(Y[3 * i + 2], w2, fma(Y[3 * i + 1], w1, fma(Y[3 * i], w0, acc[6 * i + c])));
         }
       }
     }
@@ -1288,27 +1289,30 @@ __global__ __launch_bounds__(64, 2) void k_schur(DeviceProblem d, double lam, do
 // into chunks of <= SCH_CAP observations / <= SCH_MAXLM landmarks and gives each block `cpb` of them.
 // k_schur reads W straight from HBM inside a dependent chain and adds its blocks into S with fp64
 // atomics (which execute at the memory side, ~1.3 TB/s chip-wide); here a wave
-//   1. loads a whole chunk with coalesced, independent loads (lane t takes observation t: its 18 W
-//      values and camera slot; lane l takes landmark l: V, gp, track start) into REGISTERS while the
+//   1. loads a whole chunk with coalesced, independent loads (lane t takes observation t: the 12 factors
+//      of its W and its camera slot; lane l takes landmark l: V, gp, track start) into REGISTERS while the
 //      pairs of the previous chunk are being multiplied (software pipeline: HBM latency is hidden),
-//   2. inverts the damped V blocks (one per lane), forms Y = W Vd^-1 ONCE per observation and parks
-//      Y | W in LDS (SYW_STRIDE doubles per observation),
-//   3. runs the pair products Y_a W_b^T out of LDS, accumulating in registers along a run of
-//      tracks with the same camera signature,
+//   2. inverts the damped V blocks (one per lane) and factors the inverse, Vd^-1 = L L^T; forms
+//      Z = W L = Jc^T (Jp L) ONCE per observation (48 multiply-adds; W itself is never formed) and parks it in LDS
+//      (SZ_STRIDE doubles per observation): W_a Vd^-1 W_b^T = Z_a Z_b^T and W_a Vd^-1 gp = Z_a (L^T gp),
+//   3. runs the pair products Z_a Z_b^T out of LDS (16-byte reads; three FMAs chained into each accumulator),
+//      accumulating in registers along a run of tracks with the same camera signature,
 //   4. at the end of a run (the host marked those steps in sch_flush: the structure is static)
 //      writes its 64 x 42 accumulators (6x6 block | 6 rhs entries per lane) as ONE contiguous
 //      contribution tile with plain coalesced stores.  k_gather_S then sums, for every S block, the
 //      rows that the host's inverted index lists for it: no atomics, no memset, and S is bitwise
 //      reproducible from run to run.
-// Algorithmic bytes are those of k_schur, but W is read from HBM exactly once.
-// Chunk shape: 40 observations / 7-column flush passes keep the kernel at 248 VGPRs and 19 KB of LDS,
-// so two waves share a SIMD (8 blocks per CU); measured against 64 / 14 / one wave per SIMD:
-// 26.3 vs 29.3 us on BASELINE configs[1], 64.6 vs 71.9 us on configs[2].
-constexpr int SCH_CAP = 40;     // observations per chunk (<= lanes of a wave)
+// Chunk shape: 64 observations with one 18-double factor each (round 1 and most of round 2: 40 observations with
+// Y = W Vd^-1 and W, 36 doubles each, in the same 19 KB of LDS) and 7-column flush passes: 235 VGPRs, two waves per
+// SIMD (8 blocks per CU).  Measured, 40 x (Y | W) -> 64 x Z -> chained FMAs: 25.2 -> 24.6 -> 22.9 us on BASELINE
+// configs[1], 58.3 -> 53.4 -> 49.3 us on configs[2], 529 -> 483 -> 447 us on configs[3] (matrix-free).  The counters
+// say why the arithmetic matters more than the traffic here: VALU-active 65 % of the SIMD cycles, LDS waits 8 %.
+constexpr int SCH_CAP = 64;     // observations per chunk (<= lanes of a wave)
 constexpr int SCH_MAXLM = 32;   // landmarks per chunk
 constexpr int SCH_MAXLEN = 10;  // longest track the staged kernel takes (55 pairs <= 64 lanes)
 constexpr int SCH_MAXCPB = 32;  // chunks per block
-constexpr int SYW_STRIDE = 38;  // Y[18] | W[18] | 2 pad doubles (rows stay 16-byte aligned)
+constexpr int SZ_STRIDE = 22;   // Z[18] | 4 pad doubles: rows stay 16-byte aligned, and the 16-byte reads of the <= 10 rows
+                                // of a track start 44 dwords apart: ten distinct 4-bank slots
 constexpr int CTR_ROW = 42;     // doubles per contribution row: 6x6 block | 6 reduced-rhs entries
 constexpr int FLUSH_NV = 7, FLUSH_STRIDE = FLUSH_NV;  // columns per flush pass (divides CTR_ROW; odd: no LDS padding needed)
 
@@ -1320,8 +1324,8 @@ template <int G, bool MF>
 __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double lam, double min_diag, int cpb,
                                                         const double* __restrict__ poses, const double* __restrict__ pts) {
   __shared__ double stage[64 * FLUSH_STRIDE];
-  __shared__ __align__(16) double sYW[SCH_CAP * SYW_STRIDE];
-  __shared__ double sVi[SCH_MAXLM * 9];  // Vd^-1 (6) | gp (3) per landmark of the chunk
+  __shared__ __align__(16) double sZ[SCH_CAP * SZ_STRIDE];  // Z = W L per observation, Vd^-1 = L L^T
+  __shared__ double sVi[SCH_MAXLM * 9];  // L (6: l00 l10 l20 l11 l21 l22) | L^T gp (3) per landmark of the chunk
   __shared__ int sFree[SCH_CAP];
   __shared__ int sKb[SCH_MAXLM + 1];
   __shared__ int sTab[3][SCH_MAXCPB + 1];  // this block's chunks: first landmark | first observation | flush bits
@@ -1455,13 +1459,24 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
     const unsigned fbits = (unsigned)sTab[2][ci - c0];
     __syncthreads();  // the pairs of the previous chunk are done with the LDS tiles
     if (lane < nc) {
+      // Vd^-1 = L L^T (Cholesky of the 3x3 inverse): the pair products are then Z_a Z_b^T with ONE 6x3 factor
+      // Z = W L per observation, and the reduced right-hand side is Z (L^T gp)
       double vi[6];
       const double det = damped_inv3(pv, per_comp ? plam : lam, min_diag, vi);
-      if (!(det > 0.0)) ++nbad;
+      const double d00 = vi[0], il00 = 1.0 / sqrt(d00);
+      const double l10 = vi[1] * il00, l20 = vi[2] * il00;
+      const double d11 = vi[3] - l10 * l10, il11 = 1.0 / sqrt(d11);
+      const double l21 = (vi[4] - l20 * l10) * il11;
+      const double d22 = vi[5] - l20 * l20 - l21 * l21;
+      const bool ok = det > 0.0 && d00 > 0.0 && d11 > 0.0 && d22 > 0.0;
+      if (!ok) ++nbad;  // the landmark then contributes nothing (finite S), and the step is refused by k_lm_decide
+      const double L6[6] = {ok ? d00 * il00 : 0.0, ok ? l10 : 0.0, ok ? l20 : 0.0, ok ? d11 * il11 : 0.0, ok ? l21 : 0.0,
+                            ok ? sqrt(d22) : 0.0};
 #pragma unroll
-      for (int i = 0; i < 6; ++i) sVi[lane * 9 + i] = vi[i];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) sVi[lane * 9 + 6 + i] = pg[i];
+      for (int i = 0; i < 6; ++i) sVi[lane * 9 + i] = L6[i];
+      sVi[lane * 9 + 6] = L6[0] * pg[0] + L6[1] * pg[1] + L6[2] * pg[2];
+      sVi[lane * 9 + 7] = L6[3] * pg[1] + L6[4] * pg[2];
+      sVi[lane * 9 + 8] = L6[5] * pg[2];
       if constexpr (MF) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) sPts[lane * 3 + i] = pP[i];
@@ -1472,10 +1487,10 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
     __syncthreads();
     if (lane < nobs) {
       const int li = plm - j0;
-      double vi[6], w18[18];
+      double jw[W_ROWS];
       if constexpr (MF) {
         const double P[3] = {sPts[li * 3], sPts[li * 3 + 1], sPts[li * 3 + 2]};
-        double r[2], Jc[12], Jp[6], zc, jw[W_ROWS];
+        double r[2], Jc[12], Jp[6], zc;
         linearize_obs(d.K, pw, P, pu, pvv, r, Jc, Jp, zc);
         if (d.loss.kind != LOSS_LINEAR) {
 #pragma unroll
@@ -1489,22 +1504,23 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
           }
         }
         w_pack(Jc, Jp, pfree >= 0, jw);
-        w_from_j(jw, w18);
       } else {
-        w_from_j(pw, w18);  // W of this observation from its stored factors
+#pragma unroll
+        for (int i = 0; i < W_ROWS; ++i) jw[i] = pw[i];  // the stored factors
       }
+      // Z = W L = Jc^T (Jp L), Jc = [-Jp | Jr]: 12 + 36 multiply-adds, W itself is never formed
+      const double l00 = sVi[li * 9], l10 = sVi[li * 9 + 1], l20 = sVi[li * 9 + 2], l11 = sVi[li * 9 + 3],
+                   l21 = sVi[li * 9 + 4], l22 = sVi[li * 9 + 5];
+      const double q0[3] = {jw[0] * l00 + jw[1] * l10 + jw[2] * l20, jw[1] * l11 + jw[2] * l21, jw[2] * l22};
+      const double q1[3] = {jw[3] * l00 + jw[4] * l10 + jw[5] * l20, jw[4] * l11 + jw[5] * l21, jw[5] * l22};
+      double* __restrict__ zrow = &sZ[lane * SZ_STRIDE];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) vi[i] = sVi[li * 9 + i];
+      for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        double y[3];
-        sym3_mul(vi, &w18[3 * i], y);
-        sYW[lane * SYW_STRIDE + 3 * i] = y[0];
-        sYW[lane * SYW_STRIDE + 3 * i + 1] = y[1];
-        sYW[lane * SYW_STRIDE + 3 * i + 2] = y[2];
-      }
-#pragma unroll
-      for (int r = 0; r < 18; ++r) sYW[lane * SYW_STRIDE + 18 + r] = w18[r];
+        for (int c = 0; c < 3; ++c) {
+          zrow[3 * i + c] = -(jw[i] * q0[c] + jw[3 + i] * q1[c]);
+          zrow[9 + 3 * i + c] = jw[6 + i] * q0[c] + jw[9 + i] * q1[c];
+        }
     }
     __syncthreads();
     if (ci + 1 < c1) issue(ci + 1);  // in flight while the pairs below are multiplied
@@ -1528,20 +1544,21 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
       act = act && fa >= 0 && fb >= 0;
       if (act) {
         cur_sym = (fa == fb) && (a0 != b0);
-        const double* __restrict__ Ya = &sYW[(kb + a0) * SYW_STRIDE];
-        const double* __restrict__ Wb = &sYW[(kb + b0) * SYW_STRIDE + 18];
+        const double* __restrict__ Ya = &sZ[(kb + a0) * SZ_STRIDE];
+        const double* __restrict__ Wb = &sZ[(kb + b0) * SZ_STRIDE];
         double Y[18];
 #pragma unroll
         for (int i = 0; i < 18; ++i) Y[i] = Ya[i];
         if (a0 == b0) {
 #pragma unroll
-          for (int i = 0; i < 6; ++i) accr[i] += Y[3 * i] * g[0] + Y[3 * i + 1] * g[1] + Y[3 * i + 2] * g[2];
+          for (int i = 0; i < 6; ++i) accr[i] = fma(Y[3 * i + 2], g[2], fma(Y[3 * i + 1], g[1], fma(Y[3 * i], g[0], accr[i])));
         }
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
           const double w0 = Wb[3 * c], w1 = Wb[3 * c + 1], w2 = Wb[3 * c + 2];
 #pragma unroll
-          for (int i = 0; i < 6; ++i) acc[6 * i + c] += Y[3 * i] * w0 + Y[3 * i + 1] * w1 + Y[3 * i + 2] * w2;
+          for (int i = 0; i < 6; ++i)  // three chained FMAs into the accumulator (a sum formed first costs a fourth instruction)
+            acc[6 * i + c] = fma(Y[3 * i + 2], w2, fma(Y[3 * i + 1], w1, fma(Y[3 * i], w0, acc[6 * i + c])));
         }
       }
     }
