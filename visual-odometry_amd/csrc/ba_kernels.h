@@ -496,7 +496,7 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_f
   }
   cost = wave_sum_dpp(cost);
   gmax = group_max<64>(gmax);
-  const double bb = wave_sum_dpp((double)nbehind), bz = wave_sum_dpp((double)nzero);
+  const double bb = (double)__popcll(__ballot(nbehind != 0)), bz = (double)__popcll(__ballot(nzero != 0));  // (0 or 1 per lane)
   if (lane == 0 && have) {
     double* sc = SCAL_MINE(d);
     atomic_add_f64(&sc[SC_COST], cost);
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_w
   }
   cost = wave_sum_dpp(cost);
   gmax = group_max<64>(gmax);
-  const double bb = wave_sum_dpp((double)nbehind), bz = wave_sum_dpp((double)nzero);
+  const double bb = (double)__popcll(__ballot(nbehind != 0)), bz = (double)__popcll(__ballot(nzero != 0));  // (0 or 1 per lane)
   if (lane == 0 && have) {
     double* sc = SCAL_MINE(d);
     atomic_add_f64(&sc[SC_COST], cost);
@@ -2522,24 +2522,26 @@ __global__ __launch_bounds__(256) void k_backsub_flat(DeviceProblem d, double la
       if (__ballot(act && nbehind != 0) != 0) comp_add(d.clm.stat, 3, co, act, (double)nbehind);
     }
   }
-  const double b0 = block_sum_256(gd, red), b1 = block_sum_256(dhd, red), b2 = block_sum_256(dn, red),
-               b3 = block_sum_256(xn, red), b4 = block_sum_256((double)nshort, red);
-  double b5 = 0.0, b6 = 0.0, b7 = 0.0;
-  if (with_cost) {
-    b5 = block_sum_256(cost, red); b6 = block_sum_256((double)nbehind, red); b7 = block_sum_256((double)nzero, red);
-  }
-  if (threadIdx.x == 0) {
-    double* sc = SCAL_MINE(d);
-    atomic_add_f64(&sc[SC_GDOT], b0);
-    atomic_add_f64(&sc[SC_DHD], b1);
-    atomic_add_f64(&sc[SC_DNORM2], b2);
-    atomic_add_f64(&sc[SC_XNORM2], b3);
-    if (b4 != 0.0) atomic_add_f64(&sc[SC_NSHORT], b4);
-    if (with_cost) {
-      atomic_add_f64(&sc[SC_COST_T], b5);
-      if (b6 != 0.0) atomic_add_f64(&sc[SC_NBEHIND_T], b6);
-      if (b7 != 0.0) atomic_add_f64(&sc[SC_ZEROZ], b7);
+  // the block's eight statistics in ONE exchange: wave sums (the three counters by ballot), one barrier, eight atomics
+  // (one block_sum_256 each cost two barriers apiece: sixteen at the end of every block)
+  __shared__ double sred[4][8];
+  {
+    const double w0 = wave_sum_dpp(gd), w1 = wave_sum_dpp(dhd), w2 = wave_sum_dpp(dn), w3 = wave_sum_dpp(xn),
+                 w5 = with_cost ? wave_sum_dpp(cost) : 0.0;
+    const double w4 = (double)__popcll(__ballot(nshort != 0)), w6 = (double)__popcll(__ballot(nbehind != 0)),
+                 w7 = (double)__popcll(__ballot(nzero != 0));
+    if (lane == 0) {
+      double* r8 = sred[wave];
+      r8[0] = w0; r8[1] = w1; r8[2] = w2; r8[3] = w3; r8[4] = w4; r8[5] = w5; r8[6] = w6; r8[7] = w7;
     }
+  }
+  __syncthreads();
+  if (tid < 8) {
+    const double v8 = (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
+    const int slot = tid == 0 ? SC_GDOT : tid == 1 ? SC_DHD : tid == 2 ? SC_DNORM2 : tid == 3 ? SC_XNORM2 : tid == 4 ? SC_NSHORT
+                     : tid == 5 ? SC_COST_T : tid == 6 ? SC_NBEHIND_T : SC_ZEROZ;
+    const bool wanted = tid < 4 || (tid == 5 && with_cost) || ((tid == 4 || (tid >= 6 && with_cost)) && v8 != 0.0);
+    if (wanted) atomic_add_f64(&SCAL_MINE(d)[slot], v8);
   }
 }
 
