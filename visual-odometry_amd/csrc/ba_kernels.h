@@ -2193,16 +2193,28 @@ __device__ __forceinline__ void pose_update_block(const DeviceProblem& d, const 
       }
     }
   }
-  const double b0 = block_sum_256(gd, red), b1 = block_sum_256(dhd, red), b2 = block_sum_256(dn, red),
-               b3 = block_sum_256(xn, red), b4 = block_max_256(gmax, red);
-  if (threadIdx.x == 0) {
-    double* sc = SCAL_MINE(d);
-    atomic_add_f64(&sc[SC_GDOT_C], b0);
-    atomic_add_f64(&sc[SC_DHD_C], b1);
-    atomic_add_f64(&sc[SC_DNORM2_C], b2);
-    atomic_add_f64(&sc[SC_XNORM2_C], b3);
-    atomic_max_nonneg(&sc[SC_GINF_C], b4);
+  // one exchange for the five statistics (a block_sum_256 each is two barriers apiece)
+  __shared__ double pred[4][5];
+  {
+    const double w0 = wave_sum_dpp(gd), w1 = wave_sum_dpp(dhd), w2 = wave_sum_dpp(dn), w3 = wave_sum_dpp(xn),
+                 w4 = group_max<64>(gmax);
+    if ((threadIdx.x & 63) == 0) {
+      double* r5 = pred[threadIdx.x >> 6];
+      r5[0] = w0; r5[1] = w1; r5[2] = w2; r5[3] = w3; r5[4] = w4;
+    }
   }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    const int t = threadIdx.x;
+    double* sc = SCAL_MINE(d);
+    if (t < 4) {
+      const int slot = t == 0 ? SC_GDOT_C : t == 1 ? SC_DHD_C : t == 2 ? SC_DNORM2_C : SC_XNORM2_C;
+      atomic_add_f64(&sc[slot], (pred[0][t] + pred[1][t]) + (pred[2][t] + pred[3][t]));
+    } else {
+      atomic_max_nonneg(&sc[SC_GINF_C], fmax(fmax(pred[0][4], pred[1][4]), fmax(pred[2][4], pred[3][4])));
+    }
+  }
+  (void)red;
 }
 
 __global__ __launch_bounds__(256) void k_pose_update(DeviceProblem d, const double* __restrict__ poses,
