@@ -1671,6 +1671,76 @@ __global__ __launch_bounds__(256) void k_gather_S(DeviceProblem d, int solver_mo
   }
 }
 
+// k_gather_S_wave: the same sums with ONE WAVE per S block (four blocks of S per workgroup, no barrier, no cross-wave
+// fold), for systems whose S blocks collect few contribution rows each: at BASELINE configs[3] an S block has 21 rows
+// of 42 doubles, and a 256-thread workgroup per block spends its time on index loads, two barriers and the fold.
+// Fixed summation order (rows in index order into eight partial sums): S stays bitwise reproducible.  No fused
+// preconditioner (the one-workgroup PCG's problems are small and keep k_gather_S).
+__global__ __launch_bounds__(256) void k_gather_S_wave(DeviceProblem d, int solver_mode) {
+  int from_slabs = 1;
+  if (solver_mode) {
+    if (d.ctrl->done) return;
+    from_slabs = d.ctrl->need_lin;
+  }
+  const int lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (idx >= d.nu + (d.C - d.Cf)) return;
+  const bool extra = idx >= d.nu;
+  const int s = extra ? 0 : idx;
+  const bool diag = extra || d.low_of[s] < 0;
+  const int f = d.urow[s];
+  const long cam27 = (long)(extra ? d.fixed_cams[idx - d.nu] : d.free2cam[f]) * 27;
+  const int r0 = d.ctr_ptr[s], cnt = extra ? 0 : d.ctr_ptr[s + 1] - r0;
+  double u = 0.0;  // lanes 0..26 of a diagonal block: this camera's U (21) | gc (6)
+  if (diag && lane < 27) {
+    if (from_slabs) {
+      const long tot = (long)d.C * 27;
+      double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0;
+      for (int k = 0; k < d.nslab_u; k += 4) {  // (nslab_u is 1 or a multiple of 4 up to 32; guard the tail anyway)
+        double* p0 = d.Ugc_slab + (long)k * tot + cam27 + lane;
+        const double a0 = p0[0], a1 = k + 1 < d.nslab_u ? p0[tot] : 0.0, a2 = k + 2 < d.nslab_u ? p0[2 * tot] : 0.0,
+                     a3 = k + 3 < d.nslab_u ? p0[3 * tot] : 0.0;
+        p0[0] = 0.0;  // consumed: clean for the next linearisation
+        if (k + 1 < d.nslab_u) p0[tot] = 0.0;
+        if (k + 2 < d.nslab_u) p0[2 * tot] = 0.0;
+        if (k + 3 < d.nslab_u) p0[3 * tot] = 0.0;
+        u0 += a0; u1 += a1; u2 += a2; u3 += a3;
+      }
+      u = (u0 + u1) + (u2 + u3);
+    } else {
+      u = d.Ugc_part[cam27 + lane];
+    }
+    d.Ugc_part[cam27 + lane] = u;
+    d.Ugc[cam27 + lane] = u;  // in the buffer the multi-GPU all-reduce sums
+  }
+  double acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+  for (int kb = 0; kb < cnt; kb += 64) {
+    const int mine = (kb + lane < cnt) ? d.ctr_row[r0 + kb + lane] : 0;
+    const int m = min(64, cnt - kb);
+    for (int k0 = 0; k0 < m; k0 += 16) {
+      double v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const long row = __builtin_amdgcn_readlane(mine, (k0 + q) & 63);
+        v[q] = (k0 + q < m && lane < CTR_ROW) ? d.contrib[row * CTR_ROW + lane] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q & 7] += v[q];
+    }
+  }
+  double sum = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  // the diagonal blocks add U (entry (i, c) of the symmetric 6x6 sits in lane sym6_index) and the rhs adds gc
+  int src = 0;
+  if (lane < 36) { const int i = lane / 6, c = lane - 6 * i; src = i <= c ? sym6_index(i, c) : sym6_index(c, i); }
+  else if (lane < CTR_ROW) src = 21 + lane - 36;
+  const double uu = __shfl(u, src);
+  if (extra || lane >= (diag ? CTR_ROW : 36)) return;
+  if (lane < 36) d.S[(long)s * 36 + lane] = diag ? sum + uu : sum;
+  else d.rhs[6L * f + lane - 36] = sum + uu;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_damp_mirror: (after the optional all-reduce) add lam * max(diag U, min_diag) to the diagonal of S,
 // invert the diagonal blocks into the block-Jacobi preconditioner, copy upper off-diagonal blocks,

@@ -117,6 +117,7 @@ struct ba_handle {
   int g_lin = 16, g_schur = 64, lpg_lin = 1, lpg_schur = 1, lpg_back = 1;
   long contrib_rows = 0;  // rows of the contribution tiles that k_schur_staged writes per launch
   bool use_flat_backsub = true;  // BA_BACKSUB_FLAT=0: the group-per-track kernel + k_cost
+  bool gather_wave = false;      // k_gather_S_wave (a wave per S block): few contribution rows per block (BA_GATHER_WAVE overrides)
   bool matrix_free = false;      // no W buffer: k_schur_staged<MF> and k_backsub_flat rebuild W (BA_MATRIX_FREE=0: stored factors)
   bool lin_win = false;          // k_linearize_win takes the linearisation (chunk tables exist; BA_LIN_WIN=0: the older kernels)
   struct PosePrior {             // ba_set_pose_prior: the caller's prior, applied by every ba_set_problem until replaced
@@ -497,7 +498,9 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
   launch_schur(h, lam);
   // the gather also inverts the damped diagonal blocks when they are final there (one GPU, one-workgroup PCG)
   const int fused_precond = h->schur_cpb > 0 && h->world == 1 && h->small_solve && d.prior.n == 0;
-  if (h->schur_cpb > 0)
+  if (h->schur_cpb > 0 && h->gather_wave && !fused_precond)
+    launch_timed(h, KT_GATHER, k_gather_S_wave, grid_for(d.nu + (d.C - d.Cf), 4), 256, d, mode);
+  else if (h->schur_cpb > 0)
     launch_timed(h, KT_GATHER, k_gather_S, d.nu + (d.C - d.Cf), 256, d, mode, lam, o.min_diag, fused_precond);
   else launch_timed(h, KT_GATHER, k_reduce_S, grid_for(d.s_slab_stride + 27L * d.C), 256, d, mode);
   const size_t red_count = (size_t)d.nu * 36 + (size_t)6 * d.Cf + (size_t)27 * d.C;
@@ -1402,6 +1405,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
       if (contrib_rows <= std::min<long>(max_rows, ((long)1 << 31) - 128)) {
         h->schur_cpb = cpb;
         h->contrib_rows = contrib_rows;
+        h->gather_wave = env_int("BA_GATHER_WAVE", (long)contributors.size() < 64L * std::max(nu, 1) ? 1 : 0) != 0;
         h->g_schur = G;
         h->d.n_chunks = n_chunks;
         for (auto& c : contributors) ctr_ptr[c.first + 1]++;
