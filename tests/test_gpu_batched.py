@@ -110,13 +110,15 @@ def test_batched_windows_match_individual_solves():
     assert abs(cost[0] - cost_o) <= 1e-6 * cost_o
 
 
-def test_batched_windows_keep_their_own_damping(monkeypatch):
+@pytest.mark.parametrize("matrix_free", ["0", "1"], ids=["stored_w", "matrix_free"])
+def test_batched_windows_keep_their_own_damping(monkeypatch, matrix_free):
     """Levenberg-Marquardt per window (CompLm): every window of a batch has its own damping sequence and its own
     accept / reject decisions, so the batch is B independent solves that share their launches.  Five ordinary windows
     and one whose guess is far off (rejected steps, damping raised): every window must land where its own solve
     (same exact reduced solver) lands, to 1e-9 in cost, the batch must take exactly as many iterations as its slowest
     window alone; with ONE damping for the batch (BA_COMP_LM=0, the round-1 behaviour) the minima are the same (1e-6)
     and the road is no shorter."""
+    monkeypatch.setenv("BA_MATRIX_FREE", matrix_free)  # both ways of getting W (batches of >= 2 M observations rebuild it)
     seeds, sizes = [0, 1, 2, 3, 4, 5], [120, 80, 200, 120, 100, 150]
     probs, scs = zip(*[_window(s, L=l) for s, l in zip(seeds, sizes)])
     probs = [dict(p) for p in probs]
