@@ -26,6 +26,7 @@
 // with identity rows (zero coupling, zero right-hand side).
 #pragma once
 #include "ba_banded.h"
+#include "ba_dense.h"
 
 constexpr int BCR_THREADS = 256;
 constexpr int BCR_MAX_M = 48;      // 8 cameras per super-block
@@ -102,6 +103,30 @@ __device__ __forceinline__ bool chol6_inverse_ld(const double* A, int ld, double
 
 constexpr int BCR_EPT = (BCR_MAX_M * BCR_MAX_M + BCR_THREADS - 1) / BCR_THREADS;  // entries of a block per thread
 
+// One item of a trailing update: out[0..6) -= sum_t a[t] * b[c * ld + t].  a, b and out point into the same LDS array,
+// so the compiler must assume that a store to out changes b: every load is issued before the first store here (one
+// LDS round trip per item instead of one per column).
+__device__ __forceinline__ void bcr_update_item(const double* a, const double* b, double* out, int ld) {
+  double x[6], bb[36], o[6];
+#pragma unroll
+  for (int t = 0; t < 6; ++t) x[t] = a[t];
+#pragma unroll
+  for (int c = 0; c < 6; ++c)
+#pragma unroll
+    for (int t = 0; t < 6; ++t) bb[6 * c + t] = b[c * ld + t];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) o[c] = out[c];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    double s = 0.0;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) s += x[t] * bb[6 * c + t];
+    o[c] -= s;
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) out[c] = o[c];
+}
+
 // The block Cholesky of the tall matrix T = [D ; Ea ; Eb^T ; I ; r^T] ((4 m + 1) x m in LDS, row stride ld): see
 // k_bcr_factor.  Called by every thread of the workgroup after a barrier that made T visible; returns with a barrier.
 __device__ __forceinline__ bool bcr_factor_T(double* T, int m, int ld, int tid) {
@@ -138,19 +163,7 @@ __device__ __forceinline__ bool bcr_factor_T(double* T, int m, int ld, int tid) 
       const int rho = w / nbc, kb = j + 1 + (w - rho * nbc), cb = 6 * kb;
       if (rho < m) { if (rho < cb) continue; }                                  // D: blocks on or below the diagonal
       else if (rho >= 3 * m && rho < 4 * m && rho - 3 * m >= c0 + 6) continue;  // identity rows still zero here
-      const double* a = T + rho * ld + c0;
-      double x[6];
-#pragma unroll
-      for (int t = 0; t < 6; ++t) x[t] = a[t];
-      double* out = T + rho * ld + cb;
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const double* b = T + (cb + c) * ld + c0;
-        double s = 0.0;
-#pragma unroll
-        for (int t = 0; t < 6; ++t) s += x[t] * b[t];
-        out[c] -= s;
-      }
+      bcr_update_item(T + rho * ld + c0, T + cb * ld + c0, T + rho * ld + cb, ld);
     }
     __syncthreads();
   }
@@ -226,10 +239,71 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_factor(double* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// Products of two m x m blocks held row-major in LDS (row stride ld), C = X Y^T, one 16 x 16 tile per wave and call on
+// v_mfma_f64_16x16x4_f64.  A thread-per-2x2-tile loop reads 1 LDS operand per multiply-add (a workgroup's four waves
+// share one 128 B / clk LDS port: 5.4 us for the products of a level at m = 30, measured with wall_clock64); the
+// matrix instruction reads 2 operands per lane for 16 multiply-adds.
+//   A operand: lane supplies X[i0 + (lane & 15)][k0 + (lane >> 4)];  B operand: Y[j0 + (lane & 15)][k0 + (lane >> 4)]
+//   result:    acc[q] = C[i0 + (lane >> 4) + 4 q][j0 + (lane & 15)]
+// Rows beyond m only feed outputs that the caller drops (the row index is clamped to stay inside the block); columns
+// k >= m (m is a multiple of 6, not of 4) are fed as zeros.
+// A wave runs FOUR tiles at a time as independent accumulator chains, interleaved k group by k group (one chain alone
+// waits out the latency of every matrix instruction: 143 ns per instruction measured).  No branch inside the loop (a
+// conditional matrix instruction makes the compiler copy the accumulators out after each one): a slot that is off
+// multiplies zeros.
+struct BcrTile {
+  const double *X, *Y;  // blocks in LDS
+  int i0, j0;           // first row of X / of Y (= column of C) of the tile
+  int kind;             // 0: off, else the caller's tag (wave-uniform)
+};
+constexpr int BCR_CHAINS = 4;
+__device__ __forceinline__ void bcr_tiles_xyt(const BcrTile (&job)[BCR_CHAINS], int m, int ld, int lane, dvec4 (&acc)[BCR_CHAINS]) {
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const double *xr[BCR_CHAINS], *yr[BCR_CHAINS];
+#pragma unroll
+  for (int s = 0; s < BCR_CHAINS; ++s) {
+    acc[s] = dvec4{0.0, 0.0, 0.0, 0.0};
+    xr[s] = job[s].X + min(job[s].i0 + l15, m - 1) * ld;
+    yr[s] = job[s].Y + min(job[s].j0 + l15, m - 1) * ld;
+  }
+  double a[BCR_CHAINS], b[BCR_CHAINS];
+#pragma unroll
+  for (int s = 0; s < BCR_CHAINS; ++s) { a[s] = xr[s][l4]; b[s] = yr[s][l4]; }   // m >= 6 > l4
+  for (int k0 = 0; k0 < m; k0 += 4) {
+    // the operands of the next k group are requested before this group's matrix instructions are issued
+    const bool in = k0 + l4 < m;
+    const int kn = k0 + 4 + l4 < m ? k0 + 4 + l4 : 0;
+    double an[BCR_CHAINS], bn[BCR_CHAINS];
+#pragma unroll
+    for (int s = 0; s < BCR_CHAINS; ++s) { an[s] = xr[s][kn]; bn[s] = yr[s][kn]; }
+#pragma unroll
+    for (int s = 0; s < BCR_CHAINS; ++s) {
+      const bool use = in && job[s].kind != 0;
+      acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(use ? a[s] : 0.0, use ? b[s] : 0.0, acc[s], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < BCR_CHAINS; ++s) { a[s] = an[s]; b[s] = bn[s]; }
+  }
+}
+// q-th tile of the lower triangle of an MT x MT grid of tiles -> (ti, tj), tj <= ti
+__device__ __forceinline__ void bcr_lower_tile(int q, int& ti, int& tj) {
+  ti = 0;
+  while ((ti + 1) * (ti + 2) / 2 <= q) ++ti;
+  tj = q - ti * (ti + 1) / 2;
+}
+constexpr int BCR_MT = (BCR_MAX_M + 15) / 16;                       // tiles per block side
+constexpr int BCR_LPW = (BCR_MT * (BCR_MT + 1) / 2 + 3) / 4;        // lower tiles per wave (4 waves)
+constexpr int BCR_FPW1 = (BCR_MT * BCR_MT + 3) / 4;                 // tiles of one full block per wave
+constexpr int BCR_FPW2 = (2 * BCR_MT * BCR_MT + 3) / 4;             // tiles of two full blocks per wave
+constexpr int BCR_ROUNDS1 = (2 * BCR_LPW + BCR_FPW1 + BCR_CHAINS - 1) / BCR_CHAINS;
+constexpr int BCR_ROUNDS2 = (2 * BCR_LPW + BCR_FPW2 + BCR_CHAINS - 1) / BCR_CHAINS;
+static_assert(BCR_THREADS == 256, "the tile schedule below assumes four waves");
+
+// ------------------------------------------------------------------------------------------------
 // k_bcr_update: one workgroup per even block e of level l = block e / 2 of level l + 1 (formulas in the header).
-// A thread owns a 2 x 2 tile of the block (10 LDS reads per 12 multiply-adds); D' is symmetric, tiles above its
-// diagonal only compute the E' part.
-__global__ __launch_bounds__(BCR_THREADS) void k_bcr_update(double* __restrict__ B, BcrPlan plan, int level, const LmCtrl* ctrl) {
+// The products run as 16 x 16 tiles on the fp64 matrix instruction (bcr_tile_xyt), a tile per wave and turn; D' is
+// symmetric: only its lower tiles are computed.
+__global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_update(double* __restrict__ B, BcrPlan plan, int level, const LmCtrl* ctrl) {
   extern __shared__ double lds[];
   if (ctrl && ctrl->done) return;
   const BcrLevel lv = plan.lv[level], nx = plan.lv[level + 1];
@@ -248,6 +322,9 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_update(double* __restrict__
   double* Dn_s = yR + m;             // [m][ld] D' staged for the mirrored write-out
   const double* __restrict__ De = B + lv.D + (long)e * mm;
   const double* __restrict__ Ee = B + lv.E + (long)e * mm;
+  const int lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int MT = (m + 15) >> 4, nlow = MT * (MT + 1) / 2, nfull = MT * MT;
+  double de[BCR_LPW][4], re = 0.0;
   {
     double v1[BCR_EPT], v2[BCR_EPT], v3[BCR_EPT];
 #pragma unroll
@@ -263,6 +340,18 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_update(double* __restrict__
     if (tid < m) {
       if (ql >= 0) y1 = B[lv.y + (long)ql * m + tid];
       if (qr >= 0) y2 = B[lv.y + (long)qr * m + tid];
+      re = B[lv.r + (long)e * m + tid];
+    }
+#pragma unroll
+    for (int p = 0; p < BCR_LPW; ++p) {  // the entries of D_e that this thread's tiles update, in flight with the rest
+      int ti, tj;
+      bcr_lower_tile(wv + 4 * p, ti, tj);
+      const int c = 16 * tj + l15;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 16 * ti + l4 + 4 * q;
+        de[p][q] = (wv + 4 * p < nlow && r < m && c < m) ? De[r * m + c] : 0.0;
+      }
     }
 #pragma unroll
     for (int u = 0; u < BCR_EPT; ++u) {
@@ -278,43 +367,65 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_update(double* __restrict__
   double* __restrict__ Dn = B + nx.D + (long)k * mm;
   double* __restrict__ En = B + nx.E + (long)k * mm;
   const bool copy_E = qr < 0;  // n odd, e = n - 1: blocks n - 1 and 0 stay coupled directly
-  const int h2 = m / 2;        // m is a multiple of 6: 2 x 2 tiles cover the block
-  for (int w = tid; w < h2 * h2; w += BCR_THREADS) {
-    const int tr = w / h2, tc = w - tr * h2, r = 2 * tr, c = 2 * tc;
-    const bool lower = tc <= tr;
-    const double *a1 = FbL + r * ld, *a1b = a1 + ld, *a2 = FaR + r * ld, *a2b = a2 + ld;
-    const double *b1 = FbL + c * ld, *b1b = b1 + ld, *b2 = FaR + c * ld, *b2b = b2 + ld, *b3 = FbR + c * ld, *b3b = b3 + ld;
-    double d00 = 0, d01 = 0, d10 = 0, d11 = 0, e00 = 0, e01 = 0, e10 = 0, e11 = 0;
-    if (lower) {
-      for (int t = 0; t < m; ++t) {
-        const double x1 = a1[t], x1b = a1b[t], x2 = a2[t], x2b = a2b[t];
-        const double p1 = b1[t], p1b = b1b[t], p2 = b2[t], p2b = b2b[t], p3 = b3[t], p3b = b3b[t];
-        d00 += x1 * p1 + x2 * p2; d01 += x1 * p1b + x2 * p2b; d10 += x1b * p1 + x2b * p2; d11 += x1b * p1b + x2b * p2b;
-        e00 += x2 * p3; e01 += x2 * p3b; e10 += x2b * p3; e11 += x2b * p3b;
+  {
+    // the jobs of this wave, in order: the two products of each of its lower tiles of D' (tiles wv, wv + 4, ...), then
+    // its tiles of E' = block (e, e + 2) = -FaR FbR^T, which continue the round robin over the waves
+    const int np = wv < nlow ? (nlow - wv + 3) / 4 : 0, q0 = (wv + 4 - nlow % 4) % 4;
+    const int nq = copy_E || q0 >= nfull ? 0 : (nfull - q0 + 3) / 4, njobs = 2 * np + nq;
+    auto make_job = [&](int n) {
+      BcrTile j{FbL, FbL, 0, 0, 0};
+      if (n < 2 * np) {
+        int ti, tj;
+        bcr_lower_tile(wv + 4 * (n >> 1), ti, tj);
+        j = (n & 1) ? BcrTile{FaR, FaR, 16 * ti, 16 * tj, 1} : BcrTile{FbL, FbL, 16 * ti, 16 * tj, 1};
+      } else if (n < njobs) {
+        const int q = q0 + 4 * (n - 2 * np), ti = q / MT, tj = q - ti * MT;
+        j = BcrTile{FaR, FbR, 16 * ti, 16 * tj, 2};
       }
-    } else {
-      for (int t = 0; t < m; ++t) {
-        const double x2 = a2[t], x2b = a2b[t], p3 = b3[t], p3b = b3b[t];
-        e00 += x2 * p3; e01 += x2 * p3b; e10 += x2b * p3; e11 += x2b * p3b;
+      return j;
+    };
+#pragma unroll
+    for (int rd = 0; rd < BCR_ROUNDS1; ++rd) {
+      if (BCR_CHAINS * rd >= njobs) break;
+      BcrTile job[BCR_CHAINS];
+      dvec4 acc[BCR_CHAINS];
+#pragma unroll
+      for (int s = 0; s < BCR_CHAINS; ++s) job[s] = make_job(BCR_CHAINS * rd + s);
+      bcr_tiles_xyt(job, m, ld, lane, acc);
+#pragma unroll
+      for (int s = 0; s < BCR_CHAINS; ++s) {
+        const int n = BCR_CHAINS * rd + s, c = job[s].j0 + l15;
+        if (job[s].kind == 1 && (s & 1) == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int r = job[s].i0 + l4 + 4 * q;
+            if (r < m && c < m) Dn_s[r * ld + c] = de[(n >> 1) < BCR_LPW ? (n >> 1) : 0][q] - (acc[s][q] + acc[s | 1][q]);
+          }
+        } else if (job[s].kind == 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int r = job[s].i0 + l4 + 4 * q;
+            if (r < m && c < m) En[r * m + c] = -acc[s][q];
+          }
+        }
       }
     }
-    const int o00 = r * m + c;
-    if (lower) {
-      const double n00 = De[o00] - d00, n01 = De[o00 + 1] - d01, n10 = De[o00 + m] - d10, n11 = De[o00 + m + 1] - d11;
-      Dn_s[r * ld + c] = n00; Dn_s[r * ld + c + 1] = n01; Dn_s[(r + 1) * ld + c] = n10; Dn_s[(r + 1) * ld + c + 1] = n11;
-    }
-    if (copy_E) { e00 = -Ee[o00]; e01 = -Ee[o00 + 1]; e10 = -Ee[o00 + m]; e11 = -Ee[o00 + m + 1]; }
-    En[o00] = -e00; En[o00 + 1] = -e01; En[o00 + m] = -e10; En[o00 + m + 1] = -e11;
+    if (copy_E)
+      for (int w = tid; w < mm; w += BCR_THREADS) En[w] = Ee[w];
   }
-  for (int r = tid; r < m; r += BCR_THREADS) {
+  if (tid < m) {
+    const int r = tid;
     double s = 0.0;
-    for (int t = 0; t < m; ++t) s += FbL[r * ld + t] * yL[t] + FaR[r * ld + t] * yR[t];
-    B[nx.r + (long)k * m + r] = B[lv.r + (long)e * m + r] - s;
+    for (int t0 = 0; t0 < m; t0 += 6) {  // m is a multiple of 6
+#pragma unroll
+      for (int u = 0; u < 6; ++u) { const int t = t0 + u; s += FbL[r * ld + t] * yL[t] + FaR[r * ld + t] * yR[t]; }
+    }
+    B[nx.r + (long)k * m + r] = re - s;
   }
   __syncthreads();
-  for (int w = tid; w < mm; w += BCR_THREADS) {  // lower triangle (and the 2 x 2 tiles on the diagonal) mirrored
+  for (int w = tid; w < mm; w += BCR_THREADS) {  // lower triangle mirrored
     const int r = w / m, c = w - r * m;
-    Dn[w] = (c <= r || (c == r + 1 && (r & 1) == 0)) ? Dn_s[r * ld + c] : Dn_s[c * ld + r];
+    Dn[w] = c <= r ? Dn_s[r * ld + c] : Dn_s[c * ld + r];
   }
 }
 
@@ -392,7 +503,7 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_backsolve(double* __restric
 //     block (k - 1, k) = -Fa_{e-1} Fb_{e-1}^T,     block (k, k + 1) = -Fa_{e+1} Fb_{e+1}^T   (or E_e where e + 1 does not exist),
 // lays them out as the tall matrix of k_bcr_factor in LDS and factors it: no round trip through memory and one launch
 // per level instead of two.
-__global__ __launch_bounds__(BCR_THREADS) void k_bcr_level(double* __restrict__ B, BcrPlan plan, int level, const LmCtrl* ctrl,
+__global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_level(double* __restrict__ B, BcrPlan plan, int level, const LmCtrl* ctrl,
                                                            double* __restrict__ badv) {
   extern __shared__ double lds[];
   if (ctrl && ctrl->done) return;
@@ -413,6 +524,9 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_level(double* __restrict__ 
   double* T = yR + m;                // [(4 m + 1)][ld] (elim), or [m][ld] as the staging copy of D'
   const double* __restrict__ De = B + lv.D + (long)e * mm;
   const double* __restrict__ Ee = B + lv.E + (long)e * mm;
+  const int lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int MT = (m + 15) >> 4, nlow = MT * (MT + 1) / 2, nfull = MT * MT;
+  double de[BCR_LPW][4], re = 0.0;
   {
     double v1[BCR_EPT], v2[BCR_EPT], v3[BCR_EPT], v4[BCR_EPT];
 #pragma unroll
@@ -428,6 +542,20 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_level(double* __restrict__ 
     if (tid < m) {
       if (ql >= 0) y1 = B[lv.y + (long)ql * m + tid];
       if (qr >= 0) y2 = B[lv.y + (long)qr * m + tid];
+      re = B[lv.r + (long)e * m + tid];
+    }
+    // the entries of D_e that this thread's tiles update: in flight with the factor blocks, not a second round trip
+    // after the products
+#pragma unroll
+    for (int p = 0; p < BCR_LPW; ++p) {
+      int ti, tj;
+      bcr_lower_tile(wv + 4 * p, ti, tj);
+      const int c = 16 * tj + l15;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 16 * ti + l4 + 4 * q;
+        de[p][q] = (wv + 4 * p < nlow && r < m && c < m) ? De[r * m + c] : 0.0;
+      }
     }
 #pragma unroll
     for (int u = 0; u < BCR_EPT; ++u) {
@@ -445,66 +573,89 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_level(double* __restrict__ 
   const bool copy_E = qr < 0;                            // n odd, e = n - 1: blocks n - 1 and 0 stay coupled directly
   const bool need_E = !elim && k == nx.n - 1;             // an even block's E' is only read where it is the last block of an
                                                          // odd count (its right neighbour is block 0: the coupling is copied)
-  const int h2 = m / 2;
-  for (int w = tid; w < h2 * h2; w += BCR_THREADS) {
-    const int tr = w / h2, tc = w - tr * h2, r = 2 * tr, c = 2 * tc;
-    const bool lower = tc <= tr;
-    const double *a1 = FbL + r * ld, *a1b = a1 + ld, *a2 = FaR + r * ld, *a2b = a2 + ld;
-    const double *b1 = FbL + c * ld, *b1b = b1 + ld, *b2 = FaR + c * ld, *b2b = b2 + ld;
-    if (lower) {
-      double d00 = 0, d01 = 0, d10 = 0, d11 = 0;
-      for (int t = 0; t < m; ++t) {
-        const double x1 = a1[t], x1b = a1b[t], x2 = a2[t], x2b = a2b[t];
-        const double p1 = b1[t], p1b = b1b[t], p2 = b2[t], p2b = b2b[t];
-        d00 += x1 * p1 + x2 * p2; d01 += x1 * p1b + x2 * p2b; d10 += x1b * p1 + x2b * p2; d11 += x1b * p1b + x2b * p2b;
+  {
+    // the jobs of this wave, in order: the two products of each of its lower tiles of D' = D_e - FbL FbL^T - FaR FaR^T
+    // (tiles wv, wv + 4, ...), then, continuing the round robin over the waves, its tiles of
+    //   elim:    Ea' = block (k - 1, k) = -FaL FbL^T  (tag 2)  and  Eb'^T = (block (k, k + 1))^T = -FbR FaR^T  (tag 3;
+    //            E_e^T where block e + 1 does not exist)
+    //   need_E:  E' = block (e, e + 2) = -FaR FbR^T  (tag 4; E_e where block e + 1 does not exist)
+    const int ntask = elim ? (copy_E ? nfull : 2 * nfull) : (need_E && !copy_E ? nfull : 0);
+    const int np = wv < nlow ? (nlow - wv + 3) / 4 : 0, q0 = (wv + 4 - nlow % 4) % 4;
+    const int nq = q0 >= ntask ? 0 : (ntask - q0 + 3) / 4, njobs = 2 * np + nq;
+    auto make_job = [&](int n) {
+      BcrTile j{FbL, FbL, 0, 0, 0};
+      if (n < 2 * np) {
+        int ti, tj;
+        bcr_lower_tile(wv + 4 * (n >> 1), ti, tj);
+        j = (n & 1) ? BcrTile{FaR, FaR, 16 * ti, 16 * tj, 1} : BcrTile{FbL, FbL, 16 * ti, 16 * tj, 1};
+      } else if (n < njobs) {
+        const int q = q0 + 4 * (n - 2 * np);
+        const bool second = q >= nfull;
+        const int qq = second ? q - nfull : q, ti = qq / MT, tj = qq - ti * MT;
+        if (!elim) j = BcrTile{FaR, FbR, 16 * ti, 16 * tj, 4};
+        else if (second) j = BcrTile{FbR, FaR, 16 * ti, 16 * tj, 3};
+        else j = BcrTile{FaL, FbL, 16 * ti, 16 * tj, 2};
       }
-      const int o00 = r * m + c;
-      T[r * ld + c] = De[o00] - d00; T[r * ld + c + 1] = De[o00 + 1] - d01;
-      T[(r + 1) * ld + c] = De[o00 + m] - d10; T[(r + 1) * ld + c + 1] = De[o00 + m + 1] - d11;
+      return j;
+    };
+#pragma unroll
+    for (int rd = 0; rd < BCR_ROUNDS2; ++rd) {
+      if (BCR_CHAINS * rd >= njobs) break;
+      BcrTile job[BCR_CHAINS];
+      dvec4 acc[BCR_CHAINS];
+#pragma unroll
+      for (int s = 0; s < BCR_CHAINS; ++s) job[s] = make_job(BCR_CHAINS * rd + s);
+      bcr_tiles_xyt(job, m, ld, lane, acc);
+#pragma unroll
+      for (int s = 0; s < BCR_CHAINS; ++s) {
+        const int n = BCR_CHAINS * rd + s, c = job[s].j0 + l15;
+        if (job[s].kind == 1 && (s & 1) == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int r = job[s].i0 + l4 + 4 * q;
+            if (r < m && c < m) T[r * ld + c] = de[(n >> 1) < BCR_LPW ? (n >> 1) : 0][q] - (acc[s][q] + acc[s | 1][q]);
+          }
+        } else if (job[s].kind == 4) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int r = job[s].i0 + l4 + 4 * q;
+            if (r < m && c < m) En[r * m + c] = -acc[s][q];
+          }
+        } else if (job[s].kind >= 2) {
+          double* out = T + (job[s].kind == 3 ? 2 * m : m) * ld;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int r = job[s].i0 + l4 + 4 * q;
+            if (r < m && c < m) out[r * ld + c] = -acc[s][q];
+          }
+        }
+      }
     }
     if (elim) {
-      // Ea' = block (k - 1, k):  [r][c] = -sum_t FaL[r][t] FbL[c][t];   Eb'^T: [r][c] = block (k, k + 1)[c][r] = -sum_t FaR[c][t] FbR[r][t]
-      const double *l0 = FaL + r * ld, *l1 = l0 + ld, *g0 = FbR + r * ld, *g1 = g0 + ld;
-      double a00 = 0, a01 = 0, a10 = 0, a11 = 0, t00 = 0, t01 = 0, t10 = 0, t11 = 0;
-      for (int t = 0; t < m; ++t) {
-        const double x0 = l0[t], x1 = l1[t], p0 = b1[t], p1 = b1b[t];
-        a00 += x0 * p0; a01 += x0 * p1; a10 += x1 * p0; a11 += x1 * p1;
-        const double y0 = g0[t], y1 = g1[t], s0 = b2[t], s1 = b2b[t];
-        t00 += y0 * s0; t01 += y0 * s1; t10 += y1 * s0; t11 += y1 * s1;
+      for (int w = tid; w < mm; w += BCR_THREADS) {
+        const int r = w / m, c = w - r * m;
+        T[(3 * m + r) * ld + c] = r == c ? 1.0 : 0.0;
+        if (copy_E) T[(2 * m + r) * ld + c] = Ee[c * m + r];
       }
-      double* A = T + (m + r) * ld + c;
-      A[0] = -a00; A[1] = -a01; A[ld] = -a10; A[ld + 1] = -a11;
-      double* Tb = T + (2 * m + r) * ld + c;
-      if (copy_E) { t00 = -Ee[c * m + r]; t01 = -Ee[(c + 1) * m + r]; t10 = -Ee[c * m + r + 1]; t11 = -Ee[(c + 1) * m + r + 1]; }
-      Tb[0] = -t00; Tb[1] = -t01; Tb[ld] = -t10; Tb[ld + 1] = -t11;
-      double* I = T + (3 * m + r) * ld + c;
-      I[0] = r == c ? 1.0 : 0.0; I[1] = 0.0; I[ld] = 0.0; I[ld + 1] = r == c ? 1.0 : 0.0;
-    } else if (need_E) {
-      const int o00 = r * m + c;
-      if (copy_E) {
-        En[o00] = Ee[o00]; En[o00 + 1] = Ee[o00 + 1]; En[o00 + m] = Ee[o00 + m]; En[o00 + m + 1] = Ee[o00 + m + 1];
-      } else {  // block (e, e + 2) = -FaR FbR^T
-        const double *b3 = FbR + c * ld, *b3b = b3 + ld;
-        double e00 = 0, e01 = 0, e10 = 0, e11 = 0;
-        for (int t = 0; t < m; ++t) {
-          const double x2 = a2[t], x2b = a2b[t], p3 = b3[t], p3b = b3b[t];
-          e00 += x2 * p3; e01 += x2 * p3b; e10 += x2b * p3; e11 += x2b * p3b;
-        }
-        En[o00] = -e00; En[o00 + 1] = -e01; En[o00 + m] = -e10; En[o00 + m + 1] = -e11;
-      }
+    } else if (need_E && copy_E) {
+      for (int w = tid; w < mm; w += BCR_THREADS) En[w] = Ee[w];
     }
   }
-  for (int r = tid; r < m; r += BCR_THREADS) {
+  if (tid < m) {
+    const int r = tid;
     double s = 0.0;
-    for (int t = 0; t < m; ++t) s += FbL[r * ld + t] * yL[t] + FaR[r * ld + t] * yR[t];
-    const double v = B[lv.r + (long)e * m + r] - s;
+    for (int t0 = 0; t0 < m; t0 += 6) {  // m is a multiple of 6
+#pragma unroll
+      for (int u = 0; u < 6; ++u) { const int t = t0 + u; s += FbL[r * ld + t] * yL[t] + FaR[r * ld + t] * yR[t]; }
+    }
+    const double v = re - s;
     if (elim) T[4 * m * ld + r] = v; else B[nx.r + (long)k * m + r] = v;
   }
   __syncthreads();
   if (!elim) {
-    for (int w = tid; w < mm; w += BCR_THREADS) {  // lower triangle (and the 2 x 2 tiles on the diagonal) mirrored
+    for (int w = tid; w < mm; w += BCR_THREADS) {  // lower triangle mirrored
       const int r = w / m, c = w - r * m;
-      Dn[w] = (c <= r || (c == r + 1 && (r & 1) == 0)) ? T[r * ld + c] : T[c * ld + r];
+      Dn[w] = c <= r ? T[r * ld + c] : T[c * ld + r];
     }
     return;
   }
@@ -616,19 +767,7 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_tail(double* __restrict__ B
     for (int w = tid; w < rows * nbc; w += BCR_THREADS) {
       const int rr = w / nbc, rho = c0 + 6 + rr, kb = j + 1 + (w - rr * nbc), cb = 6 * kb;
       if (rho < cb) continue;  // lower triangle (the right-hand-side row is below everything)
-      const double* a = T + rho * ld + c0;
-      double x[6];
-#pragma unroll
-      for (int t = 0; t < 6; ++t) x[t] = a[t];
-      double* out = T + rho * ld + cb;
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const double* b = T + (cb + c) * ld + c0;
-        double s = 0.0;
-#pragma unroll
-        for (int t = 0; t < 6; ++t) s += x[t] * b[t];
-        out[c] -= s;
-      }
+      bcr_update_item(T + rho * ld + c0, T + cb * ld + c0, T + rho * ld + cb, ld);
     }
     __syncthreads();
   }
