@@ -54,10 +54,12 @@ def test_cyclic_reduction_step_matches_oracle(make):
 
 
 @pytest.mark.parametrize("C,d", [(13, 5), (17, 5), (21, 5), (25, 5), (29, 5), (33, 5), (37, 5), (41, 5),   # 3 ... 10 blocks of 4
-                                 (120, 3), (121, 4), (123, 7), (200, 6), (257, 5)])
+                                 (120, 3), (121, 4), (123, 7), (200, 6), (257, 5),
+                                 (90, 2), (148, 8), (152, 8)])   # 1, 7 and 7 or 8 cameras per block: 1 x 1 and 3 x 3 matrix-instruction tiles
 def test_cyclic_reduction_block_counts_and_bandwidths(C, d):
     """C - 1 free cameras in super-blocks of d - 1: every small block count (levels with an odd count, an even count, the
-    merged two-block level, the single last block), padded blocks (C - 1 not a multiple), bandwidths 2 ... 6."""
+    merged two-block level, the single last block), padded blocks (C - 1 not a multiple), bandwidths 1 ... 8 (block sizes
+    6 ... 48: every tile count of the matrix-instruction products, with and without padding inside the 16-wide tiles)."""
     L = 20 * C
     out, info = _step(scenes.ring_scene(C, L, d), 1e-2)
     assert info["band_segments"] == (C - 1) // (d - 1)
