@@ -325,6 +325,7 @@ __global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_update(double* __restric
   const int lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int MT = (m + 15) >> 4, nlow = MT * (MT + 1) / 2, nfull = MT * MT;
   double de[BCR_LPW][4], re = 0.0;
+  const int rrow = tid - 3 * 64;  // r' is formed by the last wave, which gets the fewest tiles: row rrow by lane rrow
   {
     double v1[BCR_EPT], v2[BCR_EPT], v3[BCR_EPT];
 #pragma unroll
@@ -340,8 +341,8 @@ __global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_update(double* __restric
     if (tid < m) {
       if (ql >= 0) y1 = B[lv.y + (long)ql * m + tid];
       if (qr >= 0) y2 = B[lv.y + (long)qr * m + tid];
-      re = B[lv.r + (long)e * m + tid];
     }
+    if (rrow >= 0 && rrow < m) re = B[lv.r + (long)e * m + rrow];
 #pragma unroll
     for (int p = 0; p < BCR_LPW; ++p) {  // the entries of D_e that this thread's tiles update, in flight with the rest
       int ti, tj;
@@ -413,8 +414,8 @@ __global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_update(double* __restric
     if (copy_E)
       for (int w = tid; w < mm; w += BCR_THREADS) En[w] = Ee[w];
   }
-  if (tid < m) {
-    const int r = tid;
+  if (rrow >= 0 && rrow < m) {
+    const int r = rrow;
     double s = 0.0;
     for (int t0 = 0; t0 < m; t0 += 6) {  // m is a multiple of 6
 #pragma unroll
@@ -527,6 +528,7 @@ __global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_level(double* __restrict
   const int lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int MT = (m + 15) >> 4, nlow = MT * (MT + 1) / 2, nfull = MT * MT;
   double de[BCR_LPW][4], re = 0.0;
+  const int rrow = tid - 3 * 64;  // r' is formed by the last wave, which gets the fewest tiles: row rrow by lane rrow
   {
     double v1[BCR_EPT], v2[BCR_EPT], v3[BCR_EPT], v4[BCR_EPT];
 #pragma unroll
@@ -542,8 +544,8 @@ __global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_level(double* __restrict
     if (tid < m) {
       if (ql >= 0) y1 = B[lv.y + (long)ql * m + tid];
       if (qr >= 0) y2 = B[lv.y + (long)qr * m + tid];
-      re = B[lv.r + (long)e * m + tid];
     }
+    if (rrow >= 0 && rrow < m) re = B[lv.r + (long)e * m + rrow];
     // the entries of D_e that this thread's tiles update: in flight with the factor blocks, not a second round trip
     // after the products
 #pragma unroll
@@ -641,8 +643,8 @@ __global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_level(double* __restrict
       for (int w = tid; w < mm; w += BCR_THREADS) En[w] = Ee[w];
     }
   }
-  if (tid < m) {
-    const int r = tid;
+  if (rrow >= 0 && rrow < m) {
+    const int r = rrow;
     double s = 0.0;
     for (int t0 = 0; t0 < m; t0 += 6) {  // m is a multiple of 6
 #pragma unroll
