@@ -482,6 +482,7 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_backsolve(double* __restric
   const int c = tid & 63, g = tid >> 6;
   if (c < m) {
     double s = 0.0;
+#pragma unroll 4
     for (int r = g; r < m; r += 4) s += sFa[r * ld + c] * xa[r] + sFb[r * ld + c] * xb[r];
     part[g][c] = s;
   }
@@ -490,7 +491,10 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_backsolve(double* __restric
   __syncthreads();
   if (tid < m) {
     double x = 0.0;
-    for (int cc = tid; cc < m; ++cc) x += sLi[tid * ld + cc] * tt[cc];
+    for (int c0 = 0; c0 < m; c0 += 6) {  // L^-T is stored with its zeros: whole rows, six loads in flight at a time
+#pragma unroll
+      for (int u = 0; u < 6; ++u) x += sLi[tid * ld + c0 + u] * tt[c0 + u];
+    }
     X[o * m + tid] = x;
     if (tid < 6 * cnt[o]) dc[6L * cam0[o] + tid] = x;
   }
