@@ -1,0 +1,58 @@
+"""The opt-in aggregation coarse space of the one-workgroup PCG (csrc/ba_coarse.h, BA_PCG_COARSE=1): same solution,
+fewer PCG iterations.  The oracle leg is the numpy LM (oracle/lm_schur_numpy.py) run to the same tolerance."""
+import numpy as np
+import pytest
+
+import scenes
+from src import _native
+from oracle import lm_schur_numpy as lm
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve(sc, monkeypatch, coarse):
+    monkeypatch.setenv("BA_PCG_COARSE", coarse)
+    C, L = len(sc["poses_gt"]), len(sc["points_gt"])
+    with _native.Solver(linear_solver=1) as s:
+        s.set_problem(C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+        assert s.reduced_solver() == "pcg_one_workgroup"
+        poses, points, rep = s.solve(sc["poses_guess"], sc["points_guess"])
+    return poses, points, rep
+
+
+@pytest.mark.parametrize("C,L,d", [(50, 2000, 10), (30, 1500, 8), (80, 4000, 6)])  # aggregates of 5, 5 and 10 cameras
+def test_coarse_space_same_solution_fewer_iterations(C, L, d, monkeypatch):
+    sc = scenes.ring_scene(C, L, d)
+    p0, x0, r0 = _solve(sc, monkeypatch, "0")
+    p1, x1, r1 = _solve(sc, monkeypatch, "1")
+    assert r1["status"] in (1, 2, 3, 4) and r1["bad_pivots"] == 0
+    assert abs(r1["cost"] - r0["cost"]) <= 1e-7 * r0["cost"]
+    # (the scale of the scene is a free gauge with one fixed camera: the estimates agree in cost, not entry by entry)
+    # the first two LM iterations run on block-Jacobi alone in both; after them the coarse space must pay
+    h0, h1 = r0["pcg_history"], r1["pcg_history"]
+    assert h0[:2] == h1[:2]
+    assert sum(h1[2:]) / max(len(h1) - 2, 1) < 0.9 * sum(h0[2:]) / max(len(h0) - 2, 1)  # config-2 shape: 0.4, 30 cameras: 0.76
+
+
+def test_coarse_space_against_the_oracle(monkeypatch):
+    sc = scenes.ring_scene(30, 600, 8)
+    poses, points, rep = _solve(sc, monkeypatch, "1")
+    ref = lm.lm_solve(sc["poses_guess"], sc["points_guess"], sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+    ref_cost = ref[2].cost
+    assert abs(rep["cost"] - ref_cost) <= 1e-6 * ref_cost
+
+
+def test_coarse_space_repeated_solves_are_independent(monkeypatch):
+    """A second solve on the same handle starts without the inverses (and the pending sums) of the first."""
+    monkeypatch.setenv("BA_PCG_COARSE", "1")
+    sc = scenes.ring_scene(50, 2000, 10)
+    with _native.Solver(linear_solver=1) as s:
+        s.set_problem(50, 2000, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+        reps = []
+        for _ in range(3):
+            s.upload_guess(sc["poses_guess"], sc["points_guess"])
+            reps.append(s.solve_resident())
+    for r in reps[1:]:
+        assert r["iterations"] == reps[0]["iterations"]
+        assert r["pcg_history"][:2] == reps[0]["pcg_history"][:2]
+        assert abs(r["cost"] - reps[0]["cost"]) <= 1e-9 * reps[0]["cost"]

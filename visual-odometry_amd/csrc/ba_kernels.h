@@ -115,6 +115,7 @@ struct DeviceProblem {
   const int* sm_slot;    // [nu]  upper slots in diagonal-major order (k_solve_small item order)
   const int* sm_desc;    // [nu][4] per item: slot, row camera i, column camera j, 27 * camera of i (one load instead of a chain)
   const int* sm_gidx;    // [nb]  k_solve_small gather list, in brow_ptr order: LDS slot offset of each block of a row
+  int c_ag, c_nc;        // coarse space of the one-workgroup PCG (ba_coarse.h): cameras per aggregate, coarse unknowns
   // connected components of the camera graph (k_solve_components)
   const int* comp_ptr;       // [n_comp + 1] into comp_cams
   const int* comp_cams;      // [Cf] free cameras grouped by component
@@ -1575,7 +1576,7 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
 // combined in a fixed order.  Reads every contribution row once: 336 B per (pair, run, block of
 // k_schur_staged).
 __global__ __launch_bounds__(256) void k_gather_S(DeviceProblem d, int solver_mode, double lam, double min_diag,
-                                                  int precond) {
+                                                  int precond, double* __restrict__ csum) {
   __shared__ double part[4][64];
   __shared__ double sblk[36];
   __shared__ double upart[8][32];
@@ -1651,6 +1652,12 @@ __global__ __launch_bounds__(256) void k_gather_S(DeviceProblem d, int solver_mo
     }
     d.S[(long)s * 36 + lane] = sum;
     if (diag && precond) sblk[lane] = sum;
+    if (csum) {  // the damped block into the coarse sums P^T (S + lam D) P of ba_coarse.h: both triangles
+      const int r = lane / 6, c = lane - 6 * r, a = f / d.c_ag, b = d.ucol[s] / d.c_ag;
+      const double v = (diag && r == c) ? sum + lam * fmax(ugc[sym6_index(r, r)], min_diag) : sum;
+      atomic_add_f64(&csum[(6 * a + r) * d.c_nc + 6 * b + c], v);
+      if (!diag) atomic_add_f64(&csum[(6 * b + c) * d.c_nc + 6 * a + r], v);
+    }
   } else {
     d.rhs[6L * f + lane - 36] = sum + ugc[21 + lane - 36];
   }
@@ -1920,6 +1927,9 @@ constexpr int SMALL_MAX_NB = 2;          // upper blocks per thread: nu <= 1024
 constexpr int SMALL_GREG = 20;           // gather offsets a row thread keeps in registers
 constexpr int SMALL_ZSTRIDE = 7;         // doubles per camera of z and r in LDS: 6 | pad (a stride of 6 doubles makes the 64-bit reads of 32 lanes share banks two by two)
 constexpr int SMALL_CSTRIDE = 13;        // doubles per SpMV slot: B z_j (6) | B^T z_i (6) | pad (bank spread)
+constexpr int SMALL_COARSE_MAX = 64;     // == COARSE_MAX (ba_coarse.h): 8 threads per row fill the workgroup
+constexpr int SMALL_COARSE_PARTS = 8;    // threads per row of the coarse inverse
+constexpr int SMALL_COARSE_K = SMALL_COARSE_MAX / SMALL_COARSE_PARTS;  // its entries per thread
 
 __device__ __forceinline__ void small_load_block(const DeviceProblem& d, int t, double lam, double min_diag,
                                                  double B[36], int& i, int& j) {
@@ -1962,9 +1972,13 @@ __device__ __forceinline__ double small_block_products(const double B[36], int i
   return q;
 }
 
-template <int NB>
+// COARSE: z = Minv r + P Sc^-1 P^T r with the aggregation coarse space of ba_coarse.h (cinv: Sc^-1 of the previous LM
+// iteration, [nc][nc] + a validity flag; null: block-Jacobi alone).  The restriction P^T r is wave-local (an aggregate
+// is 5 or 10 of the 10 cameras of a wave), the nc x nc product is spread over 8 nc threads with the matrix in
+// registers, the prolongation is a read of the aggregate's 6-vector: two more barriers per iteration.
+template <int NB, bool COARSE>
 __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, double lam, double min_diag,
-                                                               double tol2, int max_iter) {
+                                                               double tol2, int max_iter, const double* __restrict__ cinv) {
   extern __shared__ double sm[];
   if (lam < 0.0) {
     if (d.ctrl->done) return;
@@ -1974,9 +1988,21 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
   double* zv = sm;                              // [Cf][7]  z = Minv r: the vector the SpMV multiplies (6 | pad)
   double* rv = zv + SMALL_ZSTRIDE * d.Cf;       // [Cf][7]  r, for the wave-local exchange
   double* red = rv + SMALL_ZSTRIDE * d.Cf;      // [8][2]
-  double* slot = red + 16;          // [nu][SMALL_CSTRIDE]
+  double* rcv = red + 16;                       // [SMALL_COARSE_MAX]  P^T r
+  double* zcv = rcv + SMALL_COARSE_MAX;         // [SMALL_COARSE_MAX]  Sc^-1 P^T r
+  double* slot = zcv + SMALL_COARSE_MAX;        // [nu][SMALL_CSTRIDE]
   int* gl = reinterpret_cast<int*>(slot + (size_t)(d.nu + 1) * SMALL_CSTRIDE);  // [nb] gather list
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nc = d.c_nc, ag = d.c_ag;
+  const bool coarse = COARSE && cinv != nullptr && cinv[nc * nc] > 0.5;  // uniform
+  double cw[COARSE ? SMALL_COARSE_K : 1];  // row tid / 8 of Sc^-1, columns tid % 8 + 8 k
+  if (COARSE) {
+#pragma unroll
+    for (int k = 0; k < SMALL_COARSE_K; ++k) {
+      const int b = (tid & (SMALL_COARSE_PARTS - 1)) + SMALL_COARSE_PARTS * k;
+      cw[k] = (coarse && tid < SMALL_COARSE_PARTS * nc && b < nc) ? cinv[(tid / SMALL_COARSE_PARTS) * nc + b] : 0.0;
+    }
+  }
 
   for (int t = tid; t < d.nb; t += SMALL_THREADS) gl[t] = d.sm_gidx[t];
   if (tid < SMALL_CSTRIDE) slot[(size_t)d.nu * SMALL_CSTRIDE + tid] = 0.0;
@@ -2024,6 +2050,36 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
     for (int k = 0; k < SMALL_GREG; ++k)
       gi[v][k] = (ent[v] >= 0 && g0[v] + k < g1[v]) ? gl[g0[v] + k] + ent[v] % 6 : d.nu * SMALL_CSTRIDE;
   auto precondition = [&]() {  // z = Minv r for this thread's rows (r of the camera is in rv), published in zv
+    if (COARSE && coarse) {
+      const int per_wave = (SMALL_ROWS_PER_WAVE / 6) / ag;  // aggregates among the 10 cameras of a wave: 2 or 1
+#pragma unroll
+      for (int v = 0; v < SMALL_VPT; ++v) {
+        const int cam0 = (wv + (SMALL_THREADS / 64) * v) * (SMALL_ROWS_PER_WAVE / 6);
+        const int al = lane / 6, comp = lane - 6 * al, a = cam0 / ag + al;
+        if (al < per_wave && 6 * a < nc) {
+          double s = 0.0;
+          for (int q = 0; q < ag; ++q) {
+            const int cam = a * ag + q;
+            if (cam < d.Cf) s += rv[SMALL_ZSTRIDE * cam + comp];
+          }
+          rcv[6 * a + comp] = s;
+        }
+      }
+      __syncthreads();
+      {  // every thread: the shuffles below need all eight lanes of a row (8 x 64 = the workgroup)
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < SMALL_COARSE_K; ++k) {
+          const int b = (tid & (SMALL_COARSE_PARTS - 1)) + SMALL_COARSE_PARTS * k;
+          s += cw[k] * rcv[b < nc ? b : 0];  // cw is zero beyond nc
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if ((tid & (SMALL_COARSE_PARTS - 1)) == 0 && tid < SMALL_COARSE_PARTS * nc) zcv[tid / SMALL_COARSE_PARTS] = s;
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int v = 0; v < SMALL_VPT; ++v)
       if (ent[v] >= 0) {
@@ -2031,6 +2087,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
         double zi = 0.0;
 #pragma unroll
         for (int c = 0; c < 6; ++c) zi += mrow[v][c] * rc[c];
+        if (COARSE && coarse) zi += zcv[6 * ((ent[v] / 6) / ag) + row6[v]];
         z[v] = zi;
         zv[zoff[v]] = zi;
       }

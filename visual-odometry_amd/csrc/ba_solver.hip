@@ -7,6 +7,7 @@
 #include "ba_banded.h"
 #include "ba_bcr.h"
 #include "ba_prior.h"
+#include "ba_coarse.h"
 
 #include <algorithm>
 #include <chrono>
@@ -165,6 +166,17 @@ struct ba_handle {
   double* dense_A = nullptr;
   int dense_nt = 0;
   size_t small_lds = 0;
+  // aggregation coarse space of the one-workgroup PCG (ba_coarse.h): built on a second stream, one LM iteration behind
+  bool coarse = false;
+  double* csum[2] = {nullptr, nullptr};  // coarse sums of the LM iterations of parity p (k_gather_S adds, k_coarse_build clears)
+  double* cinv[2] = {nullptr, nullptr};  // Sc^-1 built from csum[p]: read by the solves of parity p, two iterations later
+  size_t coarse_lds = 0;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_coarse[2] = {nullptr, nullptr};
+  int coarse_seq = 0;                      // solver-mode reduced solves enqueued in the current lm_solve
+  int coarse_dirty[2] = {-1, -1};          // the iteration whose gather added to csum[p], -1: csum[p] is clear
+  bool coarse_inflight[2] = {false, false};  // a build on buffer p has been launched and not yet been seen complete
+  bool coarse_have[2] = {false, false};      // cinv[p] holds an inverse
 
   DeviceProblem d{};
   std::vector<void*> allocs;  // everything to hipFree
@@ -289,6 +301,7 @@ void collect_spans(ba_handle* h, const LmCtrl& c) {
 }
 
 void free_problem(ba_handle* h) {
+  if (h->side) (void)hipStreamSynchronize(h->side);  // a coarse build may still be reading the buffers freed below
   for (int i = 0; i < BA_KERNEL_CLASSES; ++i) { h->ktime_ms[i] = 0.0; h->kcount[i] = 0; }
   for (void* p : h->allocs) (void)hipFree(p);
   h->allocs.clear();
@@ -495,13 +508,30 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
   DeviceProblem& d = h->d;
   const ba_options& o = h->opt;
   const int mode = lam < 0.0;
+  // coarse space of the one-workgroup PCG (ba_coarse.h): buffer p = parity of this LM iteration
+  double* csum_arg = nullptr;
+  const double* cinv_arg = nullptr;
+  if (mode && h->coarse) {
+    const int p = h->coarse_seq & 1;
+    if (h->coarse_inflight[p]) {  // launched two iterations ago: complete, as a rule
+      if (hipEventQuery(h->ev_coarse[p]) != hipSuccess) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_coarse[p], 0));
+      h->coarse_inflight[p] = false;
+      h->coarse_have[p] = true;
+    }
+    if (h->coarse_dirty[p] < 0) {  // clear (never used, or consumed by a build): this iteration's sums go there
+      csum_arg = h->csum[p];
+      h->coarse_dirty[p] = h->coarse_seq;
+    }
+    if (h->coarse_have[p]) cinv_arg = h->cinv[p];
+    ++h->coarse_seq;
+  }
   launch_schur(h, lam);
   // the gather also inverts the damped diagonal blocks when they are final there (one GPU, one-workgroup PCG)
   const int fused_precond = h->schur_cpb > 0 && h->world == 1 && h->small_solve && d.prior.n == 0;
   if (h->schur_cpb > 0 && h->gather_wave && !fused_precond)
     launch_timed(h, KT_GATHER, k_gather_S_wave, grid_for(d.nu + (d.C - d.Cf), 4), 256, d, mode);
   else if (h->schur_cpb > 0)
-    launch_timed(h, KT_GATHER, k_gather_S, d.nu + (d.C - d.Cf), 256, d, mode, lam, o.min_diag, fused_precond);
+    launch_timed(h, KT_GATHER, k_gather_S, d.nu + (d.C - d.Cf), 256, d, mode, lam, o.min_diag, fused_precond, csum_arg);
   else launch_timed(h, KT_GATHER, k_reduce_S, grid_for(d.s_slab_stride + 27L * d.C), 256, d, mode);
   const size_t red_count = (size_t)d.nu * 36 + (size_t)6 * d.Cf + (size_t)27 * d.C;
   if (h->world > 1)  // the one exchange step of the path: partial S, reduced rhs, U / gc summed over the shards
@@ -599,10 +629,13 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
   }
   if (h->small_solve) {
     if (!fused_precond) launch_timed(h, KT_OTHER, k_block_precond, grid_for(d.Cf, 64), 64, d, lam, o.min_diag);
-    if (d.nu <= SMALL_THREADS)
-      launch_timed_lds(h, KT_PCG, k_solve_small<1>, 1, SMALL_THREADS, h->small_lds, d, lam, o.min_diag, tol2, o.pcg_max_iter);
+    const double* cin = cinv_arg;
+    if (h->coarse)
+      launch_timed_lds(h, KT_PCG, k_solve_small<1, true>, 1, SMALL_THREADS, h->small_lds, d, lam, o.min_diag, tol2, o.pcg_max_iter, cin);
+    else if (d.nu <= SMALL_THREADS)
+      launch_timed_lds(h, KT_PCG, k_solve_small<1, false>, 1, SMALL_THREADS, h->small_lds, d, lam, o.min_diag, tol2, o.pcg_max_iter, cin);
     else
-      launch_timed_lds(h, KT_PCG, k_solve_small<2>, 1, SMALL_THREADS, h->small_lds, d, lam, o.min_diag, tol2, o.pcg_max_iter);
+      launch_timed_lds(h, KT_PCG, k_solve_small<2, false>, 1, SMALL_THREADS, h->small_lds, d, lam, o.min_diag, tol2, o.pcg_max_iter, cin);
     *pcg_iters = -1;  // lives in scal[SC_PCGIT]
     // every rank solved the same all-reduced system with a solver whose summation order is fixed (no
     // atomics): the camera step is bit-identical on all ranks and needs no broadcast
@@ -735,7 +768,13 @@ int lm_solve(ba_handle* h, ba_report* rep) {
   const int check_every =
       (h->small_solve || h->comp_solve || h->dense_solve || h->banded_solve || h->bcr_solve) ? std::max(1, o.lm_check_every) : 1;
   h->mirror->seq = 0;
-  int enq = 0, rc;
+  if (h->coarse) {  // no build of an earlier solve in flight, clear sums, no inverse yet
+    HIP_TRY(h, hipStreamSynchronize(h->side));
+    HIP_TRY(h, hipMemsetAsync(h->csum[0], 0, (size_t)2 * d.c_nc * d.c_nc * sizeof(double), h->stream));
+    h->coarse_seq = 0;
+    for (int p = 0; p < 2; ++p) { h->coarse_dirty[p] = -1; h->coarse_inflight[p] = h->coarse_have[p] = false; }
+  }
+  int enq = 0, observed = 0, rc;
   bool done = false;
   // On the staged path with a solver that keeps no state in the scalar block, the accumulators clean themselves
   // (k_gather_S zeroes the U / gc slabs it has summed, k_lm_decide the statistics it has folded): one memset per
@@ -767,6 +806,18 @@ int lm_solve(ba_handle* h, ba_report* rep) {
         launch_timed(h, KT_DECIDE, k_lm_decide, 1, 256, d, (const double*)nullptr, 1, h->mirror_dev, enq + 1);
       }
     }
+    if (h->coarse) {
+      // the iterations that the host has SEEN finish left final coarse sums: their inverses are built on the second
+      // stream, beside the iterations just enqueued (launched after them: the launch costs the host a few us)
+      for (int p = 0; p < 2; ++p)
+        if (h->coarse_dirty[p] >= 0 && h->coarse_dirty[p] < observed && !h->coarse_inflight[p]) {
+          k_coarse_build<<<1, COARSE_THREADS, h->coarse_lds, h->side>>>(d, h->csum[p], h->cinv[p]);
+          note_launch(h);
+          HIP_TRY(h, hipEventRecord(h->ev_coarse[p], h->side));
+          h->coarse_inflight[p] = true;
+          h->coarse_dirty[p] = -1;
+        }
+    }
     // k_lm_decide stores the control head into pinned host memory and then raises seq: spin on it (a copy +
     // stream synchronisation costs ~20 us of idle GPU per iteration); long iterations fall back to a blocking wait
     const auto spin_until = clk::now() + std::chrono::milliseconds(2);
@@ -780,6 +831,7 @@ int lm_solve(ba_handle* h, ba_report* rep) {
       }
     }
     done = h->mirror->head.done != 0;
+    observed = enq;
   }
   HIP_TRY(h, hipMemcpyAsync(&c, d.ctrl, sizeof c, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -897,6 +949,9 @@ void ba_destroy(ba_handle* h) {
   if (h->ctrl_host) (void)hipHostFree(h->ctrl_host);
   if (h->mirror) (void)hipHostFree(h->mirror);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->ev_coarse)
+    if (e) (void)hipEventDestroy(e);
+  if (h->side) (void)hipStreamDestroy(h->side);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -1447,15 +1502,41 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
       const int sl = bslot[e];
       sm_gidx[e] = sl < nu ? inv_sm[sl] * SMALL_CSTRIDE : inv_sm[up_of_low[sl - nu - gap_blocks]] * SMALL_CSTRIDE + 6;
     }
-    h->small_lds = ((size_t)2 * SMALL_ZSTRIDE * Cf + 16 + (size_t)(nu + 1) * SMALL_CSTRIDE) * sizeof(double) +
+    h->small_lds = ((size_t)2 * SMALL_ZSTRIDE * Cf + 16 + 2 * SMALL_COARSE_MAX + (size_t)(nu + 1) * SMALL_CSTRIDE) * sizeof(double) +
                    (size_t)nb * sizeof(int);
     h->small_solve = env_int("BA_SMALL_SOLVE", 1) && 6 * Cf <= SMALL_MAX_ROWS &&
                      nu <= SMALL_MAX_NB * SMALL_THREADS && h->small_lds <= 160 * 1024;
     if (h->small_solve && h->small_lds > 64 * 1024) {
-      HIP_TRY(h, hipFuncSetAttribute((const void*)k_solve_small<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      HIP_TRY(h, hipFuncSetAttribute((const void*)k_solve_small<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)h->small_lds));
-      HIP_TRY(h, hipFuncSetAttribute((const void*)k_solve_small<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      HIP_TRY(h, hipFuncSetAttribute((const void*)k_solve_small<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)h->small_lds));
+      HIP_TRY(h, hipFuncSetAttribute((const void*)k_solve_small<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)h->small_lds));
+    }
+    // coarse space (ba_coarse.h): opt-in (BA_PCG_COARSE=1).  At config 2 it takes the PCG iterations of a solve from 110
+    // to 66 and k_solve_small from 40 to 34 us, but an iteration with it costs 2.7 us against 1.5 (two more barriers and
+    // the coarse product), and the LM iteration as a whole is no faster (132 against 129 us): DESIGN.md section 5
+    h->coarse = h->small_solve && nu <= SMALL_THREADS && h->world == 1 && h->prior.cams.empty() && h->schur_cpb > 0 &&
+                Cf <= 100 && env_int("BA_PCG_COARSE", 0) != 0;
+    h->d.c_ag = h->d.c_nc = 0;
+    if (h->coarse) {
+      const int ag = Cf <= 50 ? 5 : 10, nc = 6 * ((Cf + ag - 1) / ag);  // nc <= 60
+      h->d.c_ag = ag;
+      h->d.c_nc = nc;
+      h->coarse_lds = (size_t)2 * nc * (nc + 1) * sizeof(double);
+      int rc2;
+      if ((rc2 = dev_alloc(h, &h->csum[0], (size_t)2 * nc * nc)) || (rc2 = dev_alloc(h, &h->cinv[0], (size_t)nc * nc + 1)) ||
+          (rc2 = dev_alloc(h, &h->cinv[1], (size_t)nc * nc + 1)))
+        return rc2;
+      h->csum[1] = h->csum[0] + (size_t)nc * nc;
+      if (h->coarse_lds > 64 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute((const void*)k_coarse_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->coarse_lds));
+      if (!h->side) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_coarse[0], hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_coarse[1], hipEventDisableTiming));
+      }
     }
   }
 
@@ -1748,6 +1829,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
       return fail(h, BA_ERR_INVALID, "cyclic reduction needs one connected problem with free cameras");
     }
     if (h->comp_solve || h->dense_solve) h->small_solve = false;
+    if (!h->small_solve) h->coarse = false;
     h->dense_nt = (6 * Cf + DT - 1) / DT;
     if (h->comp_solve && h->comp_lds > 32 * 1024)
       HIP_TRY(h, hipFuncSetAttribute((const void*)k_solve_components, hipFuncAttributeMaxDynamicSharedMemorySize,
