@@ -2172,101 +2172,9 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_solve_components: dense Cholesky solve of the reduced camera system, one wave per connected
-// component of the camera graph (cameras that share no landmark, directly or through a chain of
-// cameras, belong to different components: S is block diagonal over them).  This is the linear solver
-// of batched local bundle adjustment (BASELINE config 5: thousands of independent 10-keyframe
-// windows solved as ONE problem) and of any problem whose components have <= COMP_MAX_CAMS free
-// cameras.  The component's S (<= 72 x 72, 41 KB) lives in LDS: assembly from the 6x6 blocks + LM
-// damping, in-place lower Cholesky (row-oriented trailing update, one row per lane), forward and
-// backward substitution.  Exact step: no PCG iterations, no preconditioner.
-// Bound: LDS latency (about 3 n dependent steps, n = 6 x cameras); reads S once (288 B per block).
+// k_solve_components (ba_components.h): dense Cholesky per connected component of the camera graph, a wave each.
 constexpr int COMP_MAX_CAMS = 12;
 
-__global__ __launch_bounds__(64) void k_solve_components(DeviceProblem d, double lam, double min_diag) {
-  extern __shared__ double sm[];
-  const bool per_comp = lam < 0.0 && d.clm.lam != nullptr;
-  if (lam < 0.0) {
-    if (d.ctrl->done) return;
-    lam = d.ctrl->lam;
-  }
-  const int comp = blockIdx.x, lane = threadIdx.x;
-  const int c0 = d.comp_ptr[comp], nc = d.comp_ptr[comp + 1] - c0, n = 6 * nc, ld = n + 1;
-  if (per_comp) {  // a damping per component; a frozen component takes no step
-    lam = d.clm.lam[comp];
-    if (d.clm.done[comp]) {
-      for (int t = lane; t < n; t += 64) d.dc[6L * d.comp_cams[c0 + t / 6] + t % 6] = 0.0;
-      if (lane == 0 && comp == 0) { d.scal[SC_PCGIT] = 0.0; d.scal[SC_DONE] = 1.0; }
-      return;
-    }
-  }
-  double* A = sm;            // [n][ld] lower triangle used
-  double* b = sm + n * ld;   // [n]
-  for (int t = lane; t < n * ld; t += 64) A[t] = 0.0;
-  __syncthreads();
-  // blocks of the component: slot (i, j), i <= j (global free-camera numbers) -> lower entry A[6 lj + c][6 li + r]
-  for (int e = d.comp_slot_ptr[comp]; e < d.comp_slot_ptr[comp + 1]; ++e) {
-    const int s = d.comp_slots[e];
-    const int li = d.comp_local[d.urow[s]], lj = d.comp_local[d.ucol[s]];
-    if (lane < 36) {
-      const int r = lane / 6, c = lane - 6 * r;
-      double v = d.S[(long)s * 36 + lane];
-      if (li == lj) {
-        if (r == c) v += lam * fmax(u_diag(d, d.urow[s], r), min_diag);
-        if (c <= r) A[(6 * li + r) * ld + 6 * li + c] = v;
-      } else {
-        A[(6 * lj + c) * ld + 6 * li + r] = v;  // lj > li: the transposed block is the lower one
-      }
-    }
-  }
-  for (int t = lane; t < n; t += 64) {
-    const int f = d.comp_cams[c0 + t / 6];
-    b[t] = -d.rhs[6L * f + t % 6];
-  }
-  __syncthreads();
-  // Cholesky A = L L^T
-  bool bad = false;
-  for (int k = 0; k < n; ++k) {
-    double piv = A[k * ld + k];
-    if (!(piv > 0.0)) { bad = true; piv = 1.0; }
-    const double inv = 1.0 / sqrt(piv);
-    __syncthreads();
-    for (int i = k + lane; i < n; i += 64) A[i * ld + k] *= inv;  // i == k: sqrt(piv)
-    __syncthreads();
-    for (int i = k + 1 + lane; i < n; i += 64) {
-      const double aik = A[i * ld + k];
-      for (int j = k + 1; j <= i; ++j) A[i * ld + j] -= aik * A[j * ld + k];
-    }
-    __syncthreads();
-  }
-  // L y = b
-  for (int k = 0; k < n; ++k) {
-    const double yk = b[k] / A[k * ld + k];
-    __syncthreads();
-    if (lane == 0) b[k] = yk;
-    for (int i = k + 1 + lane; i < n; i += 64) b[i] -= A[i * ld + k] * yk;
-    __syncthreads();
-  }
-  // L^T x = y
-  for (int k = n - 1; k >= 0; --k) {
-    const double xk = b[k] / A[k * ld + k];
-    __syncthreads();
-    if (lane == 0) b[k] = xk;
-    for (int j = lane; j < k; j += 64) b[j] -= A[k * ld + j] * xk;
-    __syncthreads();
-  }
-  for (int t = lane; t < n; t += 64) {
-    const int f = d.comp_cams[c0 + t / 6];
-    d.dc[6L * f + t % 6] = b[t];
-  }
-  if (lane == 0) {
-    if (bad) {
-      if (per_comp) d.clm.stat[CL_STRIDE * comp + 4] = 1.0;  // only this component's step is refused
-      else atomic_add_f64(&SCAL_MINE(d)[SC_BADV], 1.0);
-    }
-    if (comp == 0) { d.scal[SC_PCGIT] = 0.0; d.scal[SC_DONE] = 1.0; }
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // pose update: trial poses = retract(poses, dc); camera part of the step statistics

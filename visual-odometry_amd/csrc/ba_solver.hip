@@ -8,6 +8,7 @@
 #include "ba_bcr.h"
 #include "ba_prior.h"
 #include "ba_coarse.h"
+#include "ba_components.h"
 
 #include <algorithm>
 #include <chrono>
@@ -1570,7 +1571,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
     h->d.n_comp = n_comp;
     free_comp = comp_id;
     const int n = 6 * max_cams;
-    h->comp_lds = ((size_t)n * (n + 1) + n) * sizeof(double);
+    h->comp_lds = comp_lds_bytes(n);
     const int want = h->opt.linear_solver;
     // AUTO: several small components (batched windows) -> Cholesky per component; one small system -> the
     // one-workgroup PCG; up to DENSE_MAX_CAMS cameras -> whole-GPU dense Cholesky; beyond -> multi-kernel PCG.
