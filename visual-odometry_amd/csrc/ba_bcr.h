@@ -48,7 +48,8 @@ struct BcrPlan {
 };
 
 // ------------------------------------------------------------------------------------------------
-// k_bcr_assemble: the damped S (upper 6x6 blocks) and -rhs into the level-0 arrays, which must be zero.
+// k_bcr_assemble: the damped S (upper 6x6 blocks) and -rhs into the level-0 arrays, which must be zero wherever this
+// kernel does not write (it writes the same entries every time: the arrays are cleared once, when they are allocated).
 //   kind[s] 0: diagonal block of a camera (lower triangle mirrored), 1: block inside a D (written twice, mirrored),
 //           2: block of an E, as stored, 3: block of an E, transposed (the loop closure: block (N - 1, 0)).
 //   dst[s]  offset of the target of entry (0, 0) (for kind 1: of the upper copy; dst2[s] the mirrored copy)

@@ -154,7 +154,7 @@ struct ba_handle {
   bool bcr_solve = false;
   BcrPlan bcr_plan{};
   double* bcr_B = nullptr;
-  size_t bcr_zero = 0;  // doubles of the level-0 arrays (cleared before every assembly)
+  size_t bcr_zero = 0;  // doubles of the level-0 arrays (cleared once, in ba_set_problem)
   size_t bcr_lds_factor = 0, bcr_lds_update = 0, bcr_lds_tail = 0, bcr_lds_level = 0;
   bool bcr_fused = true;  // BA_BCR_FUSED=0: k_bcr_update and k_bcr_factor as separate launches at every level
   const long *bcr_dst = nullptr, *bcr_dst2 = nullptr, *bcr_rdst = nullptr, *bcr_pad = nullptr;
@@ -551,7 +551,6 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
     const LmCtrl* ctrl = mode ? d.ctrl : nullptr;
     const BcrPlan& pl = h->bcr_plan;
     double* B = h->bcr_B;
-    HIP_TRY(h, hipMemsetAsync(B, 0, h->bcr_zero * sizeof(double), h->stream));
     launch_timed(h, KT_PCG, k_bcr_assemble, grid_for((long)d.nu * 36 + 6L * d.Cf + h->bcr_npad), 256, d, B, pl.m, h->bcr_dst,
                  h->bcr_dst2, h->bcr_kind, h->bcr_rdst, h->bcr_pad, h->bcr_npad, lam, o.min_diag, mode);
     if (h->bcr_fused && pl.n_levels > 0) {
@@ -1758,7 +1757,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
         pl.m = m; pl.N = N;
         long off = 0;
         int n_l = N, nl = 0;
-        // level-0 arrays first and contiguous: one memset clears them
+        // level-0 arrays first and contiguous: one memset (in ba_set_problem) clears them
         std::vector<int> ns;  // block counts: elimination levels while more than the tail's share is left, then the tail
         const int n_tail = std::max(2, BCR_TAIL_ROWS / m);
         for (int t = N;; t = (t + 1) / 2) { ns.push_back(t); if (t <= n_tail) break; }
@@ -1923,6 +1922,9 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
         (rc = dev_upload(h, &h->bcr_rdst, h->h_brdst)) || (rc = dev_upload(h, &h->bcr_pad, h->h_bpad)) ||
         (rc = dev_upload(h, &h->bcr_cam0, h->h_bcam0)) || (rc = dev_upload(h, &h->bcr_cnt, h->h_bcnt)))
       return rc;
+    // the level-0 arrays are cleared ONCE: k_bcr_assemble writes the same entries in every solve (the block pattern is
+    // fixed) and nothing else writes there, so what it does not write stays zero
+    HIP_TRY(h, hipMemset(h->bcr_B, 0, h->bcr_zero * sizeof(double)));
   }
   d.clm = CompLm{};
   if (h->comp_lm) {
