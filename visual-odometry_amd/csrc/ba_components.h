@@ -11,7 +11,7 @@
 // sweep then gives x = L^-T y.  9 block steps for a 10-keyframe window where the first version took 54 column steps of
 // three barriers each plus 108 substitution steps; the assembly reads the component's block list in one round (a lane
 // per block for the slot / camera numbers, then the 36 entries of eight blocks in flight at a time) where it walked the
-// list block by block, three dependent loads each.  Config 5 (1024 windows): 140 -> see DESIGN.md section 5.
+// list block by block, three dependent loads each.  Config 5 (1024 windows): 140 -> 43 us per launch.
 // Bound: LDS latency of ~3 nb dependent phases; reads S once (288 B per block).
 #pragma once
 #include "ba_bcr.h"
