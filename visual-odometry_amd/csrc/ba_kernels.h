@@ -1683,11 +1683,23 @@ __global__ __launch_bounds__(256) void k_gather_S(DeviceProblem d, int solver_mo
 // of 42 doubles, and a 256-thread workgroup per block spends its time on index loads, two barriers and the fold.
 // Fixed summation order (rows in index order into eight partial sums): S stays bitwise reproducible.  No fused
 // preconditioner (the one-workgroup PCG's problems are small and keep k_gather_S).
-__global__ __launch_bounds__(256) void k_gather_S_wave(DeviceProblem d, int solver_mode) {
+// `bcr` (solver mode, one GPU, no prior: S is final here): the damped blocks and -rhs also go straight into the level-0
+// arrays of the cyclic reduction (what k_bcr_assemble does from S in a launch of its own: ba_bcr.h has the layout).
+struct BcrScatter {
+  double* B;                  // null: off
+  const long *dst, *dst2, *rdst;
+  const unsigned char* kind;
+  int m;
+  double min_diag;
+};
+
+__global__ __launch_bounds__(256) void k_gather_S_wave(DeviceProblem d, int solver_mode, BcrScatter bcr) {
   int from_slabs = 1;
+  double lam = 0.0;
   if (solver_mode) {
     if (d.ctrl->done) return;
     from_slabs = d.ctrl->need_lin;
+    lam = d.ctrl->lam;
   }
   const int lane = threadIdx.x & 63;
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1746,6 +1758,29 @@ __global__ __launch_bounds__(256) void k_gather_S_wave(DeviceProblem d, int solv
   if (extra || lane >= (diag ? CTR_ROW : 36)) return;
   if (lane < 36) d.S[(long)s * 36 + lane] = diag ? sum + uu : sum;
   else d.rhs[6L * f + lane - 36] = sum + uu;
+  if (bcr.B) {
+    if (lane < 36) {
+      const int r = lane / 6, c = lane - 6 * r, k = bcr.kind[s], m = bcr.m;
+      double v = diag ? sum + uu : sum;
+      double* blk = bcr.B + bcr.dst[s];
+      if (k == 0) {  // a camera's diagonal block: uu of a diagonal entry is U's diagonal entry (Marquardt scaling)
+        if (c <= r) {
+          if (r == c) v += lam * fmax(uu, bcr.min_diag);
+          blk[r * m + c] = v;
+          blk[c * m + r] = v;
+        }
+      } else if (k == 1) {
+        blk[r * m + c] = v;
+        bcr.B[bcr.dst2[s] + c * m + r] = v;
+      } else if (k == 2) {
+        blk[r * m + c] = v;
+      } else {
+        blk[c * m + r] = v;
+      }
+    } else {
+      bcr.B[bcr.rdst[f] + lane - 36] = -(sum + uu);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

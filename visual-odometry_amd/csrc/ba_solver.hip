@@ -155,6 +155,7 @@ struct ba_handle {
   BcrPlan bcr_plan{};
   double* bcr_B = nullptr;
   size_t bcr_zero = 0;  // doubles of the level-0 arrays (cleared once, in ba_set_problem)
+  bool bcr_direct = false;  // k_gather_S_wave writes the level-0 arrays itself (no k_bcr_assemble launch in solver mode)
   size_t bcr_lds_factor = 0, bcr_lds_update = 0, bcr_lds_tail = 0, bcr_lds_level = 0;
   bool bcr_fused = true;  // BA_BCR_FUSED=0: k_bcr_update and k_bcr_factor as separate launches at every level
   const long *bcr_dst = nullptr, *bcr_dst2 = nullptr, *bcr_rdst = nullptr, *bcr_pad = nullptr;
@@ -529,8 +530,13 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
   launch_schur(h, lam);
   // the gather also inverts the damped diagonal blocks when they are final there (one GPU, one-workgroup PCG)
   const int fused_precond = h->schur_cpb > 0 && h->world == 1 && h->small_solve && d.prior.n == 0;
+  // one GPU, solver mode, no prior: S is final in the gather, which then fills the cyclic reduction's arrays itself
+  const bool bcr_direct = mode && h->bcr_solve && h->bcr_direct && h->gather_wave && h->schur_cpb > 0 && !fused_precond;
+  BcrScatter bsc{};
+  if (bcr_direct)
+    bsc = BcrScatter{h->bcr_B, h->bcr_dst, h->bcr_dst2, h->bcr_rdst, h->bcr_kind, h->bcr_plan.m, o.min_diag};
   if (h->schur_cpb > 0 && h->gather_wave && !fused_precond)
-    launch_timed(h, KT_GATHER, k_gather_S_wave, grid_for(d.nu + (d.C - d.Cf), 4), 256, d, mode);
+    launch_timed(h, KT_GATHER, k_gather_S_wave, grid_for(d.nu + (d.C - d.Cf), 4), 256, d, mode, bsc);
   else if (h->schur_cpb > 0)
     launch_timed(h, KT_GATHER, k_gather_S, d.nu + (d.C - d.Cf), 256, d, mode, lam, o.min_diag, fused_precond, csum_arg);
   else launch_timed(h, KT_GATHER, k_reduce_S, grid_for(d.s_slab_stride + 27L * d.C), 256, d, mode);
@@ -551,8 +557,9 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
     const LmCtrl* ctrl = mode ? d.ctrl : nullptr;
     const BcrPlan& pl = h->bcr_plan;
     double* B = h->bcr_B;
-    launch_timed(h, KT_PCG, k_bcr_assemble, grid_for((long)d.nu * 36 + 6L * d.Cf + h->bcr_npad), 256, d, B, pl.m, h->bcr_dst,
-                 h->bcr_dst2, h->bcr_kind, h->bcr_rdst, h->bcr_pad, h->bcr_npad, lam, o.min_diag, mode);
+    if (!bcr_direct)
+      launch_timed(h, KT_PCG, k_bcr_assemble, grid_for((long)d.nu * 36 + 6L * d.Cf + h->bcr_npad), 256, d, B, pl.m, h->bcr_dst,
+                   h->bcr_dst2, h->bcr_kind, h->bcr_rdst, h->bcr_pad, h->bcr_npad, lam, o.min_diag, mode);
     if (h->bcr_fused && pl.n_levels > 0) {
       // factor of level 0; then one launch per level: the update of level l with the factor of level l + 1; the last
       // update leaves the tail system
@@ -1925,6 +1932,13 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
     // the level-0 arrays are cleared ONCE: k_bcr_assemble writes the same entries in every solve (the block pattern is
     // fixed) and nothing else writes there, so what it does not write stays zero
     HIP_TRY(h, hipMemset(h->bcr_B, 0, h->bcr_zero * sizeof(double)));
+    // the padded diagonal entries are 1 in every solve: written here once, for the gather that fills the arrays directly
+    if (!h->h_bpad.empty()) {
+      std::vector<double> level0(h->bcr_zero, 0.0);
+      for (long p : h->h_bpad) level0[(size_t)p] = 1.0;
+      HIP_TRY(h, hipMemcpy(h->bcr_B, level0.data(), level0.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    h->bcr_direct = h->world == 1 && h->prior.cams.empty() && env_int("BA_BCR_DIRECT", 1) != 0;
   }
   d.clm = CompLm{};
   if (h->comp_lm) {
