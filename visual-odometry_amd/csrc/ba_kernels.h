@@ -1601,9 +1601,17 @@ __global__ __launch_bounds__(256) void k_gather_S(DeviceProblem d, int solver_mo
     if (e < 27) {
       if (from_slabs) {
         const long tot = (long)d.C * 27;
-        for (int k = g; k < d.nslab_u; k += 8) {
-          u += d.Ugc_slab[(long)k * tot + cam27 + e];
-          d.Ugc_slab[(long)k * tot + cam27 + e] = 0.0;  // consumed: clean for the next linearisation (no memset per iteration)
+        // four slabs of this group per round: the loads are issued before the stores that clear them (the compiler
+        // cannot move a load of the array over a store to it: one round trip per slab otherwise)
+        for (int k = g; k < d.nslab_u; k += 32) {
+          double* p0 = d.Ugc_slab + (long)k * tot + cam27 + e;
+          const bool h1 = k + 8 < d.nslab_u, h2 = k + 16 < d.nslab_u, h3 = k + 24 < d.nslab_u;
+          const double a0 = p0[0], a1 = h1 ? p0[8 * tot] : 0.0, a2 = h2 ? p0[16 * tot] : 0.0, a3 = h3 ? p0[24 * tot] : 0.0;
+          p0[0] = 0.0;  // consumed: clean for the next linearisation (no memset per iteration)
+          if (h1) p0[8 * tot] = 0.0;
+          if (h2) p0[16 * tot] = 0.0;
+          if (h3) p0[24 * tot] = 0.0;
+          u += a0; u += a1; u += a2; u += a3;
         }
       } else if (g == 0) {
         u = d.Ugc_part[cam27 + e];
