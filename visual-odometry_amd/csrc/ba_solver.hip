@@ -788,7 +788,7 @@ int lm_solve(ba_handle* h, ba_report* rep) {
   // solve instead of one per iteration.
   const bool self_cleaning =
       h->schur_cpb > 0 && (h->small_solve || h->comp_solve || h->dense_solve || h->banded_solve || h->bcr_solve);
-  while (!done && enq < o.max_iters) {
+  auto enqueue_batch = [&]() -> int {
     const int nb = std::min(check_every, o.max_iters - enq);
     for (int i = 0; i < nb; ++i, ++enq) {
       h->span_iter = enq;
@@ -813,6 +813,20 @@ int lm_solve(ba_handle* h, ba_report* rep) {
         launch_timed(h, KT_DECIDE, k_lm_decide, 1, 256, d, (const double*)nullptr, 1, h->mirror_dev, enq + 1);
       }
     }
+    return BA_OK;
+  };
+  // One batch AHEAD: the host puts the next batch into the stream before it waits for the current one, so the GPU never
+  // idles through the round trip (k_lm_decide -> pinned memory -> host -> six launches: 8 us per iteration at config
+  // 2, the only gap of an iteration in the kernel trace).  The batch that turns out to follow termination exits at the
+  // first instruction of each kernel (~15 us once per solve).  One GPU only: with several ranks that batch would also
+  // run its collectives.
+  const bool ahead = h->world == 1 && !h->coarse && env_int("BA_LM_AHEAD", 1) != 0;
+  if (o.max_iters > 0 && (rc = enqueue_batch())) return rc;
+  int wait_end = enq;  // the host waits until iterations [0, wait_end) have decided
+  while (wait_end > 0) {
+    const int waiting = wait_end;
+    if (ahead && enq < o.max_iters && (rc = enqueue_batch())) return rc;
+    wait_end = enq;
     if (h->coarse) {
       // the iterations that the host has SEEN finish left final coarse sums: their inverses are built on the second
       // stream, beside the iterations just enqueued (launched after them: the launch costs the host a few us)
@@ -828,17 +842,23 @@ int lm_solve(ba_handle* h, ba_report* rep) {
     // k_lm_decide stores the control head into pinned host memory and then raises seq: spin on it (a copy +
     // stream synchronisation costs ~20 us of idle GPU per iteration); long iterations fall back to a blocking wait
     const auto spin_until = clk::now() + std::chrono::milliseconds(2);
-    while (__atomic_load_n(&h->mirror->seq, __ATOMIC_ACQUIRE) != enq) {
+    while (__atomic_load_n(&h->mirror->seq, __ATOMIC_ACQUIRE) < waiting) {
       if (clk::now() > spin_until) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        if (__atomic_load_n(&h->mirror->seq, __ATOMIC_ACQUIRE) != enq)
+        if (__atomic_load_n(&h->mirror->seq, __ATOMIC_ACQUIRE) < waiting)
           return check_launches(h, "solve") ? BA_ERR_DEVICE
                                             : fail(h, BA_ERR_DEVICE, "the LM control block did not reach the host");
         break;
       }
     }
     done = h->mirror->head.done != 0;
-    observed = enq;
+    observed = waiting;
+    if (done) break;
+    if (wait_end == waiting) {  // nothing further in the stream (not ahead, or the iteration cap was reached)
+      if (enq >= o.max_iters) break;
+      if ((rc = enqueue_batch())) return rc;
+      wait_end = enq;
+    }
   }
   HIP_TRY(h, hipMemcpyAsync(&c, d.ctrl, sizeof c, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
