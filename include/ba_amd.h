@@ -31,7 +31,9 @@
 extern "C" {
 #endif
 
-#define BA_AMD_VERSION 100 /* 0.1.0 */
+#define BA_AMD_VERSION 101 /* 0.1.1: ba_report gained bad_pivots / guard_rejections / shortened_steps, BA_KERNEL_CLASSES
+                              went from 6 to 8 (ba_get_kernel_times writes 8 entries), ba_comm_info is new: a caller built
+                              against version 100 must be rebuilt (compare ba_version() with the header it was built with) */
 #define BA_HISTORY 128     /* per-iteration history entries kept in ba_report: the first BA_HISTORY - 1 iterations and,
                               in the last entry, the most recent one (a solve may run longer; n_history stops at 128) */
 
@@ -220,8 +222,8 @@ int ba_evaluate(ba_handle* h, const double* poses, const double* points, double*
 
 /* Residuals and cost WITHOUT any allocation.  No counterpart in the reference (which allocates freely: every call
  * of BundleAdjustment.residual_function builds new arrays, bundle_adjustment.py:41-87); this entry point is for
- * callers that cannot call hipMalloc: code under HIP graph capture, tight serving loops that evaluate the residual
- * as a callback, harnesses that forbid allocation.  It is ba_evaluate without a handle and without ba_set_problem:
+ * callers that cannot call hipMalloc: tight serving loops that evaluate the residual as a callback, harnesses that
+ * forbid allocation.  (NOT for use under stream capture: it makes blocking copies on the default stream.)  It is ba_evaluate without a handle and without ba_set_problem:
  * the same residual arithmetic on the observations in the caller's order, camera 0 being the fixed pose
  * (its quaternion is normalised only if off by more than 1e-6, the others always, as in ba_evaluate), plain
  * squared loss.  Everything it needs on the device (staged copies of the inputs, the residuals, per-block partial
@@ -229,6 +231,7 @@ int ba_evaluate(ba_handle* h, const double* poses, const double* points, double*
  * ends; it calls no hipMalloc / hipFree and creates no stream (default stream, blocking copies).
  * Limits: n_cams <= BA_STATIC_MAX_CAMS, n_pts <= BA_STATIC_MAX_PTS, n_obs <= BA_STATIC_MAX_OBS; beyond them it
  * returns BA_ERR_INVALID and the caller uses ba_evaluate.  device = HIP ordinal, -1 = current device.
+ * The caller's current HIP device is the same after the call as before it (the call switches to `device` and back).
  * err (may be NULL) receives the message for a non-zero status (there is no handle to ask).
  * Calls on one GPU share that GPU's array: the library serialises them with a process-wide lock, so calls from
  * several threads are safe but do not overlap; calls from different PROCESSES use different copies. */
@@ -303,6 +306,9 @@ int ba_set_kernel_timing(ba_handle* h, int32_t on);
  * collectives. */
 int ba_comm_unique_id(char* id128);
 int ba_comm_init(ba_handle* h, int32_t rank, int32_t world, const char* id128);
+/* Rank and size of the handle's communicator as RCCL itself reports them (ncclCommUserRank / ncclCommCount); 0 and 1
+ * for a handle without one.  No reference counterpart; bench.py's `n_gpus` is this figure. */
+int ba_comm_info(const ba_handle* h, int32_t* rank, int32_t* world);
 
 /* Which solver ba_set_problem chose for the reduced camera system: 0 multi-kernel PCG, 1 one-workgroup PCG,
  * 2 whole-GPU dense Cholesky, 3 banded + arrow Cholesky, 4 dense Cholesky per connected component (batched

@@ -122,6 +122,18 @@ ncclResult_t ncclCommDestroy(ncclComm_t c) {
   return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t c, int* count) {
+  if (!c || !count) return ncclInvalidArgument;
+  *count = c->world;
+  return ncclSuccess;
+}
+
+ncclResult_t ncclCommUserRank(const ncclComm_t c, int* rank) {
+  if (!c || !rank) return ncclInvalidArgument;
+  *rank = c->rank;
+  return ncclSuccess;
+}
+
 ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataType_t type, ncclRedOp_t op,
                            ncclComm_t c, hipStream_t stream) {
   if (type != ncclDouble || (op != ncclSum && op != ncclMax)) die("all-reduce flavour not handled by the shim");

@@ -264,7 +264,8 @@ def test_batched_at_config5_size():
     """BASELINE configs[4] at its stated size: 1024 windows of 10 keyframes x 100 landmarks (1 024 000 observations) in
     one call.  Every window: its cost fell, is 0.5 |r|^2 of its own residuals, sits at the noise level (0.5 px per
     axis), first keyframe untouched; a sample of windows against the oracle's LM run on that window alone (1e-6 in
-    cost: the windows share one damping sequence and one termination test, so each must still reach its own minimum)."""
+    cost: every window runs its own damping sequence, accept / reject decisions and ftol test (CompLm), so each must
+    reach its own minimum whatever the others do)."""
     B, L = 1024, 100
     probs, scs = zip(*[_window(s, L=L) for s in range(B)])
     intr = scs[0]["intr"]

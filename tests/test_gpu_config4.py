@@ -8,6 +8,10 @@ this size.  Parity is therefore pinned in two steps: the LM path of the HIP solv
 iteration by iteration, on a down-scaled scene with the same 3.8 mm geometry; and size-independent properties at full
 size, at the reference's tolerances (bundle_adjustment.py:207-209) and at the library's defaults."""
 
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -85,3 +89,19 @@ def test_config4_full_size_properties(config4, tolerances):
         assert rep2["cost"] <= rep["cost"] * (1 + 1e-12) and rep["cost"] - rep2["cost"] <= 1e-2 * rep["cost"]
     print(f"config 4 at {tolerances} tolerances: {rep['iterations']} iterations ({rep['accepted']} accepted, "
           f"{rep['guard_rejections']} guard rejections, {rep['shortened_steps']} shortened landmark steps), {rep['solve_ms']:.0f} ms, cost {rep['cost']:.6f}, status {rep['status_name']}")
+
+
+def test_config4_is_reproducible_across_processes():
+    """The full-size solve at the reference's tolerances, in two fresh processes: the same iteration count, the same
+    accept / reject sequence and a bit-identical cost (round 2: 680 to 1900 iterations and 2.4e-5 of the cost between
+    two runs, from the arrival order of fp64 atomics; round 3 sums U / g_c and the statistics in a fixed order)."""
+    worker = os.path.join(os.path.dirname(__file__), "_determinism_worker.py")
+    outs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, worker, "10000", "2000000", "5", "1e-6"], capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1], outs
+    it, status, cost_hex, digest = outs[0].split()
+    assert int(it) > 50 and int(status) in (1, 2, 3)
+    print("config 4, two processes:", outs[0])

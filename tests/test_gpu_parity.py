@@ -261,15 +261,18 @@ def test_error_mapping(golden):
 
 
 def test_single_rank_communicator_path_matches_plain_solve():
-    """The multi-GPU code path (RCCL all-reduce of [S | rhs | U,gc], broadcast of the camera step,
-    all-reduce of the statistics) with a one-rank communicator must reproduce the plain solve."""
+    """The multi-GPU code path (RCCL all-reduce of [S | rhs | U,gc], every rank solving the same all-reduced system in
+    a fixed summation order -- no broadcast of the camera step --, all-reduce of the statistics) with a one-rank
+    communicator must reproduce the plain solve; ba_comm_info reports what the communicator itself says."""
     sc = scenes.ring_scene(50, 2000, 10)
     C, L = len(sc["poses_guess"]), len(sc["points_guess"])
     with _native.Solver() as s:
         s.set_problem(C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
         P0, X0, rep0 = s.solve(sc["poses_guess"], sc["points_guess"])
     with _native.Solver() as s:
+        assert s.comm_info() == (0, 1)  # no communicator yet
         s.comm_init(0, 1, _native.comm_unique_id())
+        assert s.comm_info() == (0, 1)  # ncclCommUserRank / ncclCommCount of the one-rank communicator
         s.set_problem(C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
         P1, X1, rep1 = s.solve(sc["poses_guess"], sc["points_guess"])
     assert rep1["iterations"] == rep0["iterations"] and rep1["status"] == rep0["status"]
@@ -383,19 +386,27 @@ def test_unstructured_visibility_matches_oracle():
 
 
 def test_run_to_run_determinism_of_the_cost():
-    """the only run-to-run noise is the arrival order of the fp64 atomics that fold U / g_c and the
-    scalar statistics (S, the Cholesky solvers and the landmark blocks are summed in a fixed order): N solves of one
-    problem in one process agree to 1e-12 relative in cost (and take the same iterations)."""
-    sc = scenes.ring_scene(50, 2000, 10)
-    C, L = len(sc["poses_guess"]), len(sc["points_guess"])
-    with _native.Solver() as s:
-        s.set_problem(C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
-        s.upload_guess(sc["poses_guess"], sc["points_guess"])
-        reps = [s.solve_resident() for _ in range(8)]
-    costs = np.array([r["cost"] for r in reps])
-    assert (costs.max() - costs.min()) <= 1e-12 * costs.min(), costs
-    assert len({r["iterations"] for r in reps}) == 1 and len({r["status"] for r in reps}) == 1
-    assert np.ptp([r["cost0"] for r in reps]) <= 1e-13 * reps[0]["cost0"]
+    """Round 3: no sum on the solver's path depends on an arrival order any more (U / g_c: per-chunk rows and a
+    fixed-order fold, k_linearize_rows / fold_u_rows; the scalar statistics: per-block partial sums and k_fold_stats; S,
+    the landmark blocks and the reduced solvers were fixed-order already).  N solves of one problem agree BIT FOR BIT:
+    cost, cost history, damping history, iteration count, poses and points -- with the one-workgroup PCG, with the
+    cyclic reduction, and with a robust loss."""
+    for C, L, d, opts in ((50, 2000, 10, {}), (240, 12000, 5, {}), (50, 2000, 10, dict(loss="huber", f_scale=1.0))):
+        sc = scenes.ring_scene(C, L, d)
+        with _native.Solver(**opts) as s:
+            s.set_problem(C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+            s.upload_guess(sc["poses_guess"], sc["points_guess"])
+            reps, states = [], []
+            for _ in range(5):
+                reps.append(s.solve_resident())
+                states.append(s.download_estimate(sc["poses_guess"], sc["points_guess"]))
+        r0 = reps[0]
+        assert r0["status"] in (1, 2, 3) and r0["iterations"] > 3
+        for r, (P, X) in zip(reps[1:], states[1:]):
+            assert r["cost"] == r0["cost"] and r["cost0"] == r0["cost0"] and r["iterations"] == r0["iterations"]
+            assert r["cost_history"] == r0["cost_history"] and r["lambda_history"] == r0["lambda_history"]
+            assert r["accepted_history"] == r0["accepted_history"] and r["pcg_history"] == r0["pcg_history"]
+            assert np.array_equal(P, states[0][0]) and np.array_equal(X, states[0][1])
 
 
 def test_residual_function_callback_paths(golden):

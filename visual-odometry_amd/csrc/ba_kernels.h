@@ -132,6 +132,16 @@ struct DeviceProblem {
   const int* lin_gslot;  // [...] its slot in the workgroup's LDS copy of U | gc, or -1 (straight to the global slab)
   const int* lin_wincam; // [workgroups][LINW_WIN] camera of each slot, -1 = unused
   int n_lin_chunks;      // 0: no chunk tables (some track is longer than LINF_MAXLM)
+  // fixed-order accumulation of U | gc and of the scalar statistics (k_linearize_rows, fold_u_rows, k_fold_stats): no
+  // atomics, so that two runs of a solve take the same LM path bit for bit
+  double* Urows;         // [3][n_urows][9] U | gc summed per (chunk, camera group of the chunk): row = index into lin_gcam
+  long n_urows;          // entries of the group tables (one sentinel per chunk included); 0: the atomics kernels linearise
+  const int* ucr_ptr;    // [C * nslab_u + 1] rows of camera c, cut into nslab_u segments: segment s is ucr_row[ucr_ptr[c * nslab_u + s] .. [+ 1])
+  const int* ucr_row;    // [...] ascending
+  double* lin_part;      // [n_lin_chunks][4] per chunk: cost, z <= 0 count, z == 0 count, max |gp|
+  double* bs_part;       // [n_bs_blocks][8] per block of k_backsub_flat: its eight statistics
+  double* pose_part;     // [n_pose_blocks][5] per pose block: the camera part of the step statistics
+  int n_bs_blocks, n_pose_blocks;
   int lin_flat;          // 1: k_linearize_flat takes the chunks (few cameras); k_backsub_flat takes them whenever they exist
   const int* sch_lm;     // [n_chunks + 1] first landmark of each k_schur_staged chunk
   const int* sch_k;      // [n_chunks + 1] first observation of each chunk (= lm_ptr[sch_lm[.]])
@@ -693,6 +703,300 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_w
     if (bb != 0.0) atomic_add_f64(&sc[SC_NBEHIND], bb);
     if (bz != 0.0) atomic_add_f64(&sc[SC_ZEROZ], bz);
     atomic_max_nonneg(&sc[SC_GINF], gmax);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_linearize_rows: the lane-per-observation linearisation WITHOUT atomics, for any number of cameras (round 3; it
+// replaces k_linearize_flat and k_linearize_win wherever the chunk tables exist).  Those two sum U | gc through LDS
+// atomics and then through fp64 atomics into privatised global slabs: the order in which the waves and workgroups
+// arrive changes the last bits of U and gc from run to run, and Levenberg-Marquardt amplifies that on a flat valley
+// (BASELINE configs[3]: 680 to 1900 iterations and 2.4e-5 of the cost between two runs of the same solve).  Here every
+// sum has ONE owner and a fixed order:
+//   * a wave takes one chunk of whole tracks (<= 64 observations), a lane per observation, exactly as before;
+//   * V, gp: rows parked in LDS, summed per track in track order (unchanged);
+//   * U | gc: every lane parks its 27 products, nine at a time, in the row that the host's permutation gives it (camera
+//     order inside the chunk); one lane per (camera group of the chunk, entry) sums that camera's consecutive rows and
+//     stores the sum, with a plain store, into row `first group of the chunk + g` of d.Urows: a row per (chunk, camera).
+//     fold_u_rows (the leading blocks of the Schur launch) then sums, for every camera, the rows that the host's
+//     inverted index lists for it, segment by segment, in ascending row order, into what used to be the slabs;
+//   * cost, the two cheirality counters and max |gp|: one plain store per chunk into d.lin_part; k_fold_stats sums them.
+// A wave touches nobody else's data: no workgroup barrier at all (the LDS serves one wave's accesses in order).
+// Algorithmic bytes: those of k_linearize_win + 216 B per (chunk, camera) row written.
+template <bool ROBUST>
+__global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_rows(DeviceProblem d, const double* __restrict__ poses,
+                                                                       const double* __restrict__ pts) {
+  __shared__ double sVg[LINF_WAVES][64 * LINF_VSTRIDE];
+  __shared__ double sP[LINF_WAVES][LINF_MAXLM * 3];
+  __shared__ int sGbeg[LINF_WAVES][65];
+  if (poses == nullptr) {  // solver mode
+    const LmCtrl* c = d.ctrl;
+    if (c->done || !c->need_lin) return;
+    poses = d.poses_buf[c->sel];
+    pts = d.pts_buf[c->sel];
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = __builtin_amdgcn_readfirstlane(blockIdx.x * LINF_WAVES + wave);
+  if (c >= d.n_lin_chunks) return;  // (no workgroup barrier below)
+  const int jb = d.lin_lm[c], je = d.lin_lm[c + 1], kb = d.lin_k[c], ke = d.lin_k[c + 1];
+  const int gb = d.lin_gptr[c], ng = d.lin_gptr[c + 1] - gb - 1;
+  const int k = kb + lane;
+  const bool act = k < ke;
+  int cam = 0, fr = -1, lm = jb, tb = 0, te = 0, pos = lane;  // pos: this observation's row in camera order
+  double u = 0.0, v = 0.0, Pl[3] = {0.0, 0.0, 1.0};
+  if (act) {
+    cam = d.o_cam[k]; fr = d.o_free[k]; lm = d.o_lm[k]; u = d.o_u[k]; v = d.o_v[k];
+    pos = d.lin_perm[k];
+  }
+  if (lane <= ng) sGbeg[wave][lane] = d.lin_gbeg[gb + lane];  // (entry ng: the sentinel = the chunk's free observations)
+  const bool lm_lane = lane < je - jb;
+  if (lm_lane) {
+    tb = d.lm_ptr[jb + lane] - kb; te = d.lm_ptr[jb + lane + 1] - kb;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Pl[i] = pts[3 * (long)(jb + lane) + i];
+  }
+  double pose[7] = {0, 0, 0, 1, 0, 0, 0};
+  if (act) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) pose[i] = poses[7 * cam + i];
+  }
+  double* myP = sP[wave];
+  double* myV = sVg[wave];
+  if (lm_lane) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) myP[3 * lane + i] = Pl[i];
+  }
+  __builtin_amdgcn_wave_barrier();  // myP, the group table
+  const bool is_free = act && fr >= 0;
+  double cost = 0.0, gmax = 0.0;
+  int nbehind = 0, nzero = 0;
+  double vg[9], Jc[12], r[2] = {0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) vg[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
+  double zc = 1e300;
+  if (act) {
+    const double P[3] = {myP[3 * (lm - jb)], myP[3 * (lm - jb) + 1], myP[3 * (lm - jb) + 2]};
+    double Jp[6];
+    linearize_obs(d.K, pose, P, u, v, r, Jc, Jp, zc);
+    nbehind += (zc <= 0.0);
+    nzero += (zc == 0.0);
+    if (!ROBUST) {
+      cost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        double sc;
+        cost += robust_scale(d.loss, r[i], sc);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Jc[6 * i + q] *= sc;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) Jp[3 * i + q] *= sc;
+      }
+    }
+    vg[0] = Jp[0] * Jp[0] + Jp[3] * Jp[3];
+    vg[1] = Jp[0] * Jp[1] + Jp[3] * Jp[4];
+    vg[2] = Jp[0] * Jp[2] + Jp[3] * Jp[5];
+    vg[3] = Jp[1] * Jp[1] + Jp[4] * Jp[4];
+    vg[4] = Jp[1] * Jp[2] + Jp[4] * Jp[5];
+    vg[5] = Jp[2] * Jp[2] + Jp[5] * Jp[5];
+    vg[6] = Jp[0] * r[0] + Jp[3] * r[1];
+    vg[7] = Jp[1] * r[0] + Jp[4] * r[1];
+    vg[8] = Jp[2] * r[0] + Jp[5] * r[1];
+    if (!is_free) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
+    }
+    if (d.W) {  // (no buffer: the consumers rebuild W themselves)
+      double* __restrict__ Wk = d.W + k;
+      const long n = d.n;
+      double jw[W_ROWS];
+      w_pack(Jc, Jp, is_free, jw);
+#pragma unroll
+      for (int i = 0; i < W_ROWS; ++i) Wk[(long)i * n] = jw[i];
+    }
+  }
+  // V, gp of the chunk's landmarks: rows parked per observation, summed per track in track order
+#pragma unroll
+  for (int i = 0; i < 9; ++i) myV[lane * LINF_VSTRIDE + i] = vg[i];
+  myV[lane * LINF_VSTRIDE + 9] = zc;
+  __builtin_amdgcn_wave_barrier();
+  if (lm_lane) {
+    const int jl = jb + lane;
+    double s9[9], zmn = 1e300;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s9[i] = 0.0;
+    for (int t = tb; t < te; ++t) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) s9[i] += myV[t * LINF_VSTRIDE + i];
+      zmn = fmin(zmn, myV[t * LINF_VSTRIDE + 9]);
+    }
+    d.zmin[jl] = zmn;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d.V[(long)i * d.L + jl] = s9[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d.gp[(long)i * d.L + jl] = s9[6 + i];
+    gmax = fmax(fabs(s9[6]), fmax(fabs(s9[7]), fabs(s9[8])));
+  }
+  // U | gc: 27 values per observation, nine at a time through the same rows; the sum of a camera group goes out as
+  // nine consecutive doubles of plane ph of d.Urows (a wave's stores of a phase are contiguous: ng * 9 doubles)
+#pragma unroll
+  for (int ph = 0; ph < 3; ++ph) {
+    __builtin_amdgcn_wave_barrier();  // the rows' previous readers are done
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+      for (int q = i; q < 6; ++q) {
+        const int e = sym6_index(i, q);
+        if (e >= 9 * ph && e < 9 * ph + 9) myV[pos * LINF_VSTRIDE + e - 9 * ph] = Jc[i] * Jc[q] + Jc[6 + i] * Jc[6 + q];
+      }
+      const int e = 21 + i;
+      if (e >= 9 * ph && e < 9 * ph + 9) myV[pos * LINF_VSTRIDE + e - 9 * ph] = Jc[i] * r[0] + Jc[6 + i] * r[1];
+    }
+    __builtin_amdgcn_wave_barrier();
+    double* __restrict__ plane = d.Urows + ((long)ph * d.n_urows + gb) * 9;
+    for (int item = lane; item < ng * 9; item += 64) {
+      const int g = item / 9, q = item - 9 * g;
+      // the rows of a camera are consecutive: four independent LDS reads in flight; fixed order
+      const int p1 = sGbeg[wave][g + 1];
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      for (int p = sGbeg[wave][g]; p < p1; p += 4) {
+        const double* row = myV + p * LINF_VSTRIDE + q;
+        const double a0 = row[0], a1 = p + 1 < p1 ? row[LINF_VSTRIDE] : 0.0, a2 = p + 2 < p1 ? row[2 * LINF_VSTRIDE] : 0.0,
+                     a3 = p + 3 < p1 ? row[3 * LINF_VSTRIDE] : 0.0;
+        s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+      }
+      plane[item] = (s0 + s1) + (s2 + s3);
+    }
+  }
+  cost = wave_sum_dpp(cost);
+  gmax = group_max<64>(gmax);
+  const double bb = (double)__popcll(__ballot(nbehind != 0)), bz = (double)__popcll(__ballot(nzero != 0));  // (0 or 1 per lane)
+  if (lane < 4) d.lin_part[4L * c + lane] = lane == 0 ? cost : lane == 1 ? bb : lane == 2 ? bz : gmax;
+}
+
+// fold_u_rows: segment `s` of camera `cam`: the sum of the rows of d.Urows that the inverted index lists for it, in
+// ascending row order, into slab s of d.Ugc_slab (which the gather kernels sum over s, as they summed the atomics'
+// slabs).  One wave: lanes 0..26 take the even rows of the segment for entry `lane`, lanes 27..53 the odd ones, eight
+// loads in flight each; the two halves are added at the end.  Every (camera, segment) is written by every
+// linearisation, rows or no rows: nothing needs clearing.
+__device__ __forceinline__ void fold_u_rows(const DeviceProblem& d, int idx, int lane) {
+  const int cam = idx / d.nslab_u, s = idx - cam * d.nslab_u;
+  const int r0 = d.ucr_ptr[idx], cnt = d.ucr_ptr[idx + 1] - r0;
+  const int h = lane >= 27 ? 1 : 0, e = lane - 27 * h, ph = e / 9, q = e - 9 * ph;  // (lanes >= 54: idle, e clamped below)
+  const bool worker = lane < 54;
+  const double* __restrict__ plane = d.Urows + (long)(worker ? ph : 0) * d.n_urows * 9 + (worker ? q : 0);
+  double acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.0;
+  for (int kb = 0; kb < cnt; kb += 64) {
+    const int mine = kb + lane < cnt ? d.ucr_row[r0 + kb + lane] : 0;
+    const int m = min(64, cnt - kb);
+    for (int k0 = 0; k0 < m; k0 += 16) {  // 16 rows per round: eight per half
+      double v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int kk = k0 + 2 * i + h;
+        const long row = __shfl(mine, kk & 63);
+        v[i] = (worker && kk < m) ? plane[row * 9] : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += v[i];
+    }
+  }
+  double sum = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  sum += __shfl(sum, (lane + 27) & 63);
+  if (lane < 27) d.Ugc_slab[((long)s * d.C + cam) * 27 + lane] = sum;
+}
+
+// the fold as a launch of its own (the path whose Schur kernel is not k_schur_staged, and the explicit-mode exports)
+__global__ __launch_bounds__(64) void k_fold_U(DeviceProblem d, int solver_mode) {
+  if (solver_mode && (d.ctrl->done || !d.ctrl->need_lin)) return;
+  fold_u_rows(d, blockIdx.x, threadIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_fold_stats: the per-chunk statistics of k_linearize_rows, the per-block statistics of k_backsub_flat and those of
+// the pose blocks, summed in a fixed order into the SCAL_SLABS copies of the scalar block that k_lm_decide (or
+// k_fold_scalars, or the host) folds as before: workgroup s sums a contiguous range of each array (a thread per
+// (entry, sub-range), then a fixed tree over the sub-ranges) and adds the result to copy s with plain read-modify-
+// writes (it is the only writer of these slots in its launch).  Replaces eight + four + five fp64 atomics per block.
+// with_lin: the linearisation's partial sums are current (solver mode: the control block knows).
+__global__ __launch_bounds__(256) void k_fold_stats(DeviceProblem d, int solver_mode, int with_lin, int with_bs) {
+  __shared__ double red_bs[4][8], red_lin[4][4];
+  if (solver_mode) {
+    if (d.ctrl->done) return;
+    with_lin = with_lin && d.ctrl->need_lin;
+  }
+  with_lin = with_lin && d.n_urows > 0;
+  with_bs = with_bs && d.n_bs_blocks > 0;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, s = blockIdx.x;
+  double* __restrict__ sc = d.scal + (size_t)s * SC_COUNT;
+  // k_backsub_flat's blocks: thread = (entry e, sub-range): sub-range q takes blocks b0 + q, b0 + q + 32, ...; a wave
+  // holds 8 sub-ranges of every entry (lanes e + 8 j): three shuffle steps fold them, the four waves meet in LDS
+  double v_bs = 0.0;
+  if (with_bs) {
+    const long b0 = (long)d.n_bs_blocks * s / SCAL_SLABS, b1 = (long)d.n_bs_blocks * (s + 1) / SCAL_SLABS;
+    const int e = tid & 7, sub = tid >> 3;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (long b = b0 + sub; b < b1; b += 128) {
+      const double* p = d.bs_part + 8 * b + e;
+      const double x0 = p[0], x1 = b + 32 < b1 ? p[8 * 32] : 0.0, x2 = b + 64 < b1 ? p[8 * 64] : 0.0, x3 = b + 96 < b1 ? p[8 * 96] : 0.0;
+      a0 += x0; a1 += x1; a2 += x2; a3 += x3;
+    }
+    v_bs = (a0 + a1) + (a2 + a3);
+    v_bs += __shfl_xor(v_bs, 8, 64);
+    v_bs += __shfl_xor(v_bs, 16, 64);
+    v_bs += __shfl_xor(v_bs, 32, 64);
+  }
+  // k_linearize_rows' chunks: (entry e of 4, sub-range of 64); entry 3 is a maximum
+  double v_lin = 0.0;
+  if (with_lin) {
+    const long b0 = (long)d.n_lin_chunks * s / SCAL_SLABS, b1 = (long)d.n_lin_chunks * (s + 1) / SCAL_SLABS;
+    const int e = tid & 3, sub = tid >> 2;
+    const bool is_max = e == 3;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (long b = b0 + sub; b < b1; b += 256) {
+      const double* p = d.lin_part + 4 * b + e;
+      const double x0 = p[0], x1 = b + 64 < b1 ? p[4 * 64] : 0.0, x2 = b + 128 < b1 ? p[4 * 128] : 0.0, x3 = b + 192 < b1 ? p[4 * 192] : 0.0;
+      if (is_max) { a0 = fmax(a0, x0); a1 = fmax(a1, x1); a2 = fmax(a2, x2); a3 = fmax(a3, x3); }
+      else { a0 += x0; a1 += x1; a2 += x2; a3 += x3; }
+    }
+    v_lin = is_max ? fmax(fmax(a0, a1), fmax(a2, a3)) : (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1) {
+      const double o = __shfl_xor(v_lin, m, 64);
+      v_lin = is_max ? fmax(v_lin, o) : v_lin + o;
+    }
+  }
+  if (lane < 8) red_bs[wv][lane] = v_bs;
+  if (lane < 4) red_lin[wv][lane] = v_lin;
+  __syncthreads();
+  // one owner thread per slot of copy s: plain read-modify-writes (other kernels' atomics into this copy are complete)
+  if (tid < 8) {
+    const int slot = tid == 0 ? SC_GDOT : tid == 1 ? SC_DHD : tid == 2 ? SC_DNORM2 : tid == 3 ? SC_XNORM2 : tid == 4 ? SC_NSHORT
+                     : tid == 5 ? SC_COST_T : tid == 6 ? SC_NBEHIND_T : SC_ZEROZ;
+    double v = (red_bs[0][tid] + red_bs[1][tid]) + (red_bs[2][tid] + red_bs[3][tid]);
+    if (tid == 7) v += (red_lin[0][2] + red_lin[1][2]) + (red_lin[2][2] + red_lin[3][2]);
+    if (v != 0.0) sc[slot] += v;
+  } else if (tid < 10) {
+    const int e = tid - 8;
+    const double v = (red_lin[0][e] + red_lin[1][e]) + (red_lin[2][e] + red_lin[3][e]);
+    if (v != 0.0) sc[e == 0 ? SC_COST : SC_NBEHIND] += v;
+  } else if (tid == 10) {
+    const double v = fmax(fmax(red_lin[0][3], red_lin[1][3]), fmax(red_lin[2][3], red_lin[3][3]));
+    if (v > 0.0) sc[SC_GINF] = fmax(sc[SC_GINF], v);
+  } else if (tid >= 16 && tid < 21 && d.n_pose_blocks > 0) {
+    // few pose blocks (cameras / 256): workgroup s takes pose blocks s, s + SCAL_SLABS, ...
+    const int t = tid - 16;
+    double v = 0.0;
+    for (int b = s; b < d.n_pose_blocks; b += SCAL_SLABS) {
+      const double x = d.pose_part[5L * b + t];
+      v = t == 4 ? fmax(v, x) : v + x;
+    }
+    const int slot = t == 0 ? SC_GDOT_C : t == 1 ? SC_DHD_C : t == 2 ? SC_DNORM2_C : t == 3 ? SC_XNORM2_C : SC_GINF_C;
+    if (t == 4) { if (v > 0.0) sc[slot] = fmax(sc[slot], v); } else if (v != 0.0) sc[slot] += v;
   }
 }
 
@@ -1323,7 +1627,8 @@ constexpr int FLUSH_NV = 7, FLUSH_STRIDE = FLUSH_NV;  // columns per flush pass 
 // earlier), V, gp and points of chunk ci + 1 are in flight while the pairs of chunk ci are multiplied.
 template <int G, bool MF>
 __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double lam, double min_diag, int cpb,
-                                                        const double* __restrict__ poses, const double* __restrict__ pts) {
+                                                        const double* __restrict__ poses, const double* __restrict__ pts,
+                                                        int n_fold) {
   __shared__ double stage[64 * FLUSH_STRIDE];
   __shared__ __align__(16) double sZ[SCH_CAP * SZ_STRIDE];  // Z = W L per observation, Vd^-1 = L L^T
   __shared__ double sVi[SCH_MAXLM * 9];  // L (6: l00 l10 l20 l11 l21 l22) | L^T gp (3) per landmark of the chunk
@@ -1331,6 +1636,16 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
   __shared__ int sKb[SCH_MAXLM + 1];
   __shared__ int sTab[3][SCH_MAXCPB + 1];  // this block's chunks: first landmark | first observation | flush bits
   __shared__ double sPts[MF ? SCH_MAXLM * 3 : 1];
+  // the last n_fold blocks of the grid fold the linearisation's U | gc rows into the slabs that the gather sums
+  // (fold_u_rows: short, memory-bound waves that fill the tail of the launch, where the Schur blocks run out; no launch
+  // of their own.  As the FIRST blocks of the grid they delayed the Schur blocks: 57.8 against 50.0 us on BASELINE configs[2])
+  const int n_schur = (int)gridDim.x - n_fold;
+  if ((int)blockIdx.x >= n_schur) {
+    if (lam < 0.0 && (d.ctrl->done || !d.ctrl->need_lin)) return;  // a re-solve with another damping: U | gc are kept
+    fold_u_rows(d, blockIdx.x - n_schur, threadIdx.x);
+    return;
+  }
+  const int sblk = blockIdx.x;  // this block's number among the Schur blocks
   if (MF && lam < 0.0) {
     poses = d.poses_buf[d.ctrl->sel];
     pts = d.pts_buf[d.ctrl->sel];
@@ -1340,7 +1655,7 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
     if (d.ctrl->done) return;
     lam = d.ctrl->lam;
   }
-  const int c0 = blockIdx.x * cpb, c1 = min(d.n_chunks, c0 + cpb);
+  const int c0 = sblk * cpb, c1 = min(d.n_chunks, c0 + cpb);
   if (c0 >= c1) return;
   const int lane = threadIdx.x;  // one wave per block
   if (lane <= c1 - c0) {
@@ -1358,7 +1673,7 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
   for (int i = 0; i < 6; ++i) accr[i] = 0.0;
   bool cur_sym = false;
   int nbad = 0;
-  double* __restrict__ out = d.contrib + (long)d.sch_blk_row[blockIdx.x] * CTR_ROW;
+  double* __restrict__ out = d.contrib + (long)d.sch_blk_row[sblk] * CTR_ROW;
   __syncthreads();
 
   auto flush = [&]() {  // wave-uniform: every lane calls it
@@ -2282,15 +2597,10 @@ __device__ __forceinline__ void pose_update_block(const DeviceProblem& d, const 
     }
   }
   __syncthreads();
-  if (threadIdx.x < 5) {
+  if (threadIdx.x < 5) {  // a plain store per statistic: k_fold_stats sums the pose blocks in a fixed order
     const int t = threadIdx.x;
-    double* sc = SCAL_MINE(d);
-    if (t < 4) {
-      const int slot = t == 0 ? SC_GDOT_C : t == 1 ? SC_DHD_C : t == 2 ? SC_DNORM2_C : SC_XNORM2_C;
-      atomic_add_f64(&sc[slot], (pred[0][t] + pred[1][t]) + (pred[2][t] + pred[3][t]));
-    } else {
-      atomic_max_nonneg(&sc[SC_GINF_C], fmax(fmax(pred[0][4], pred[1][4]), fmax(pred[2][4], pred[3][4])));
-    }
+    d.pose_part[5L * cam_block + t] = t < 4 ? (pred[0][t] + pred[1][t]) + (pred[2][t] + pred[3][t])
+                                            : fmax(fmax(pred[0][4], pred[1][4]), fmax(pred[2][4], pred[3][4]));
   }
   (void)red;
 }
@@ -2626,13 +2936,8 @@ __global__ __launch_bounds__(256) void k_backsub_flat(DeviceProblem d, double la
     }
   }
   __syncthreads();
-  if (tid < 8) {
-    const double v8 = (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
-    const int slot = tid == 0 ? SC_GDOT : tid == 1 ? SC_DHD : tid == 2 ? SC_DNORM2 : tid == 3 ? SC_XNORM2 : tid == 4 ? SC_NSHORT
-                     : tid == 5 ? SC_COST_T : tid == 6 ? SC_NBEHIND_T : SC_ZEROZ;
-    const bool wanted = tid < 4 || (tid == 5 && with_cost) || ((tid == 4 || (tid >= 6 && with_cost)) && v8 != 0.0);
-    if (wanted) atomic_add_f64(&SCAL_MINE(d)[slot], v8);
-  }
+  if (tid < 8)  // a plain store per statistic: k_fold_stats sums the blocks in a fixed order (no atomics)
+    d.bs_part[8L * blockIdx.x + tid] = (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
 }
 
 // Copy the untouched (unobserved) landmarks [L_obs, L) into the trial buffer.

@@ -40,6 +40,8 @@ struct Rccl {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclBroadcast) Broadcast = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
@@ -63,7 +65,8 @@ Rccl* rccl_load() {
 #define RCCL_SYM(name)                                                        \
   r.name = reinterpret_cast<decltype(r.name)>(dlsym(lib, "nccl" #name));      \
   if (!r.name) return nullptr;
-  RCCL_SYM(GetUniqueId) RCCL_SYM(CommInitRank) RCCL_SYM(CommDestroy) RCCL_SYM(AllReduce) RCCL_SYM(Broadcast)
+  RCCL_SYM(GetUniqueId) RCCL_SYM(CommInitRank) RCCL_SYM(CommDestroy) RCCL_SYM(CommCount) RCCL_SYM(CommUserRank)
+  RCCL_SYM(AllReduce) RCCL_SYM(Broadcast)
   RCCL_SYM(AllGather) RCCL_SYM(GroupStart) RCCL_SYM(GroupEnd) RCCL_SYM(GetErrorString)
 #undef RCCL_SYM
   r.lib = lib;
@@ -121,7 +124,8 @@ struct ba_handle {
   bool use_flat_backsub = true;  // BA_BACKSUB_FLAT=0: the group-per-track kernel + k_cost
   bool gather_wave = false;      // k_gather_S_wave (a wave per S block): few contribution rows per block (BA_GATHER_WAVE overrides)
   bool matrix_free = false;      // no W buffer: k_schur_staged<MF> and k_backsub_flat rebuild W (BA_MATRIX_FREE=0: stored factors)
-  bool lin_win = false;          // k_linearize_win takes the linearisation (chunk tables exist; BA_LIN_WIN=0: the older kernels)
+  bool lin_win = false;          // k_linearize_win takes the linearisation (BA_LIN_ROWS=0 BA_LIN_WIN=1: round 2's kernel, atomics)
+  bool lin_rows = false;         // k_linearize_rows takes it: U | gc and the statistics summed in a fixed order (chunk tables exist)
   struct PosePrior {             // ba_set_pose_prior: the caller's prior, applied by every ba_set_problem until replaced
     std::vector<int> cams;
     std::vector<double> ref, H, g;
@@ -226,9 +230,11 @@ int fail(ba_handle* h, int code, const char* fmt, ...) {
 #define HIP_TRY(h, expr)                                                                        \
   do {                                                                                          \
     hipError_t e_ = (expr);                                                                     \
-    if (e_ != hipSuccess)                                                                       \
+    if (e_ != hipSuccess) {                                                                     \
+      (void)hipGetLastError(); /* reported here: must not resurface as a "failed launch" */     \
       return fail(h, e_ == hipErrorOutOfMemory ? BA_ERR_NOMEM : BA_ERR_DEVICE, "%s failed: %s", \
                   #expr, hipGetErrorString(e_));                                                \
+    }                                                                                           \
   } while (0)
 
 enum { KT_LIN = 0, KT_SCHUR, KT_BACKSUB, KT_COST, KT_PCG, KT_OTHER, KT_GATHER, KT_DECIDE };
@@ -240,8 +246,15 @@ static_assert(KT_DECIDE + 1 == BA_KERNEL_CLASSES, "kernel classes");
     if (r_ != ncclSuccess) return fail(h, BA_ERR_DEVICE, "%s failed: %s", #expr, (h)->rccl->GetErrorString(r_)); \
   } while (0)
 
-// A launch that the runtime refuses (bad grid or LDS size, an earlier sticky error) leaves no trace in the stream:
-// remember the first such error; the entry points turn it into BA_ERR_DEVICE at their next synchronisation.
+// A launch that the runtime refuses (bad grid or LDS size) leaves no trace in the stream: remember the first such
+// error; the entry points turn it into BA_ERR_DEVICE at their next synchronisation.  HIP's "last error" is per host
+// thread and stays set until somebody reads it: every entry point that launches kernels calls begin_launches() first,
+// so that an error left behind by an EARLIER call on this thread (a failed hipMalloc of another handle, somebody
+// else's HIP code) is not taken for a refused launch of this one.
+inline void begin_launches(ba_handle* h) {
+  (void)hipGetLastError();
+  h->launch_err = hipSuccess;
+}
 inline void note_launch(ba_handle* h) {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess && h->launch_err == hipSuccess) h->launch_err = e;
@@ -381,6 +394,12 @@ inline size_t linf_lds_bytes(int C) {
 // poses / pts == nullptr: solver mode (state and run/skip decision come from the device-side LM control)
 void launch_linearize(ba_handle* h, const double* poses, const double* pts) {
   const DeviceProblem& d = h->d;
+  if (h->lin_rows) {
+    const int grid = grid_for(d.n_lin_chunks, LINF_WAVES);
+    if (d.loss.kind == LOSS_LINEAR) launch_timed(h, KT_LIN, k_linearize_rows<false>, grid, 64 * LINF_WAVES, d, poses, pts);
+    else launch_timed(h, KT_LIN, k_linearize_rows<true>, grid, 64 * LINF_WAVES, d, poses, pts);
+    return;
+  }
   if (h->lin_win) {
     const int grid = grid_for(d.n_lin_chunks, LINF_WAVES);
     if (d.loss.kind == LOSS_LINEAR) launch_timed(h, KT_LIN, k_linearize_win<false>, grid, 64 * LINF_WAVES, d, poses, pts);
@@ -448,23 +467,26 @@ void launch_schur(ba_handle* h, double lam) {
   const int G = h->g_schur, lpg = h->lpg_schur;
   const double md = h->opt.min_diag;
   if (h->schur_cpb > 0) {
-    const int cpb = h->schur_cpb, grid = grid_for(d.n_chunks, cpb);
+    // the leading n_fold blocks sum the U | gc rows of k_linearize_rows into the slabs (fold_u_rows): a block per
+    // (camera, segment)
+    const int n_fold = h->lin_rows ? d.C * d.nslab_u : 0;
+    const int cpb = h->schur_cpb, grid = grid_for(d.n_chunks, cpb) + n_fold;
     // explicit mode (lam >= 0): the point that ba_debug_linearization staged in buffer 0
     const double* P = lam < 0.0 ? nullptr : (const double*)d.poses_buf[0];
     const double* X = lam < 0.0 ? nullptr : (const double*)d.pts_buf[0];
     if (h->matrix_free) {
       switch (G) {
-        case 8: launch_timed(h, KT_SCHUR, k_schur_staged<8, true>, grid, 64, d, lam, md, cpb, P, X); break;
-        case 16: launch_timed(h, KT_SCHUR, k_schur_staged<16, true>, grid, 64, d, lam, md, cpb, P, X); break;
-        case 32: launch_timed(h, KT_SCHUR, k_schur_staged<32, true>, grid, 64, d, lam, md, cpb, P, X); break;
-        default: launch_timed(h, KT_SCHUR, k_schur_staged<64, true>, grid, 64, d, lam, md, cpb, P, X); break;
+        case 8: launch_timed(h, KT_SCHUR, k_schur_staged<8, true>, grid, 64, d, lam, md, cpb, P, X, n_fold); break;
+        case 16: launch_timed(h, KT_SCHUR, k_schur_staged<16, true>, grid, 64, d, lam, md, cpb, P, X, n_fold); break;
+        case 32: launch_timed(h, KT_SCHUR, k_schur_staged<32, true>, grid, 64, d, lam, md, cpb, P, X, n_fold); break;
+        default: launch_timed(h, KT_SCHUR, k_schur_staged<64, true>, grid, 64, d, lam, md, cpb, P, X, n_fold); break;
       }
     } else {
       switch (G) {
-        case 8: launch_timed(h, KT_SCHUR, k_schur_staged<8, false>, grid, 64, d, lam, md, cpb, P, X); break;
-        case 16: launch_timed(h, KT_SCHUR, k_schur_staged<16, false>, grid, 64, d, lam, md, cpb, P, X); break;
-        case 32: launch_timed(h, KT_SCHUR, k_schur_staged<32, false>, grid, 64, d, lam, md, cpb, P, X); break;
-        default: launch_timed(h, KT_SCHUR, k_schur_staged<64, false>, grid, 64, d, lam, md, cpb, P, X); break;
+        case 8: launch_timed(h, KT_SCHUR, k_schur_staged<8, false>, grid, 64, d, lam, md, cpb, P, X, n_fold); break;
+        case 16: launch_timed(h, KT_SCHUR, k_schur_staged<16, false>, grid, 64, d, lam, md, cpb, P, X, n_fold); break;
+        case 32: launch_timed(h, KT_SCHUR, k_schur_staged<32, false>, grid, 64, d, lam, md, cpb, P, X, n_fold); break;
+        default: launch_timed(h, KT_SCHUR, k_schur_staged<64, false>, grid, 64, d, lam, md, cpb, P, X, n_fold); break;
       }
     }
     return;
@@ -501,7 +523,8 @@ int clear_accumulators(ba_handle* h, bool with_u) {
 // U V W gc gp at (poses, pts) [explicit mode] or at the current estimate if it moved [solver mode]
 void enqueue_linearize(ba_handle* h, const double* poses, const double* pts) {
   launch_linearize(h, poses, pts);
-  if (h->schur_cpb > 0) return;  // staged path: k_gather_S sums the U / gc slabs
+  if (h->schur_cpb > 0) return;  // staged path: the Schur launch folds the U | gc rows, k_gather_S sums the slabs
+  if (h->lin_rows) { k_fold_U<<<h->d.C * h->d.nslab_u, 64, 0, h->stream>>>(h->d, poses == nullptr); note_launch(h); }
   k_reduce_U<<<grid_for(27L * h->C, 16), 256, 0, h->stream>>>(h->d, poses == nullptr); note_launch(h);
 }
 
@@ -677,6 +700,10 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
 void enqueue_trial(ba_handle* h, double lam, const double* poses, const double* pts, double* poses_t, double* pts_t) {
   if (!launch_backsub(h, lam, pts, pts_t, poses, poses_t))
     launch_cost(h, poses_t, pts_t, SC_COST_T, SC_NBEHIND_T, nullptr);
+  // the per-chunk / per-block partial statistics of k_linearize_rows, k_backsub_flat and the pose blocks, summed in a
+  // fixed order into the copies of the scalar block (no atomics: the LM path is the same in every run)
+  launch_timed(h, KT_DECIDE, k_fold_stats, SCAL_SLABS, 256, h->d, lam < 0.0 ? 1 : 0, h->lin_rows ? 1 : 0,
+               h->flat_chunks > 0 && h->use_flat_backsub ? 1 : 0);
   if (h->d.prior.n > 0) {
     k_prior_trial<<<1, 128, 0, h->stream>>>(h->d, poses, (const double*)poses_t);
     note_launch(h);
@@ -749,6 +776,7 @@ int lm_solve(ba_handle* h, ba_report* rep) {
   rep->setup_ms = h->setup_ms;
   LmCtrl& c = *h->ctrl_host;
   std::memset(&c, 0, sizeof c);
+  begin_launches(h);
   c.ftol = o.ftol; c.xtol = o.xtol; c.gtol = o.gtol;
   c.lambda_min = o.lambda_min; c.lambda_max = o.lambda_max; c.accept_ratio = o.accept_ratio;
   c.max_iters = o.max_iters; c.guard_cheirality = o.guard_cheirality;
@@ -772,8 +800,12 @@ int lm_solve(ba_handle* h, ba_report* rep) {
     }
   }
 
+  // (with the coarse space a build on the side stream rewrites cinv[p] once the host has SEEN iteration coarse_dirty[p]
+  // finish: with one iteration per batch the iteration in flight always has the other parity; longer batches would
+  // let the build race the solves of its own parity that are still queued, so the coarse space polls every iteration)
   const int check_every =
-      (h->small_solve || h->comp_solve || h->dense_solve || h->banded_solve || h->bcr_solve) ? std::max(1, o.lm_check_every) : 1;
+      h->coarse ? 1
+                : (h->small_solve || h->comp_solve || h->dense_solve || h->banded_solve || h->bcr_solve) ? std::max(1, o.lm_check_every) : 1;
   h->mirror->seq = 0;
   if (h->coarse) {  // no build of an earlier solve in flight, clear sums, no inverse yet
     HIP_TRY(h, hipStreamSynchronize(h->side));
@@ -1022,6 +1054,19 @@ int ba_comm_init(ba_handle* h, int32_t rank, int32_t world, const char* id128) {
   h->rank = rank;
   h->world = world;
   free_problem(h);  // a problem set before the communicator existed has a rank-local pattern
+  return BA_OK;
+}
+
+int ba_comm_info(const ba_handle* h, int32_t* rank, int32_t* world) {
+  if (!h || !rank || !world) return BA_ERR_INVALID;
+  *rank = 0;
+  *world = 1;
+  if (!h->comm) return BA_OK;  // no communicator: one GPU
+  int n = 0, r = 0;  // what the communicator itself reports, not what ba_comm_init was told
+  if (h->rccl->CommCount(h->comm, &n) != ncclSuccess || h->rccl->CommUserRank(h->comm, &r) != ncclSuccess)
+    return BA_ERR_DEVICE;
+  *rank = r;
+  *world = n;
   return BA_OK;
 }
 
@@ -1373,13 +1418,20 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
   std::vector<int> lin_gptr(1, 0), lin_gbeg, lin_gcam, lin_gslot, lin_wincam;
   // (with <= LINF_MAXC cameras k_linearize_flat, whose LDS copy holds every camera, is the faster one: 17.5 vs 19.4 us
   // on BASELINE configs[1]; beyond, this kernel against k_linearize<G>: 58.6 vs 70.6 us on configs[2], 604 vs 840 on [3])
-  h->lin_win = h->flat_chunks > 0 && env_int("BA_LIN_WIN", h->lin_cpw > 0 ? 0 : 1) != 0;
-  if (h->lin_win) {
+  // Round 3: k_linearize_rows takes every problem that has chunk tables (any number of cameras): no atomics, the same
+  // bits in every run.  BA_LIN_ROWS=0 brings back round 2's kernels (k_linearize_flat / k_linearize_win: LDS and global
+  // atomics) for timing comparisons.
+  h->lin_rows = h->flat_chunks > 0 && env_int("BA_LIN_ROWS", 1) != 0;
+  if (h->lin_rows) h->lin_cpw = 0;
+  h->lin_win = !h->lin_rows && h->flat_chunks > 0 && env_int("BA_LIN_WIN", h->lin_cpw > 0 ? 0 : 1) != 0;
+  std::vector<int> ucr_ptr(1, 0), ucr_row;
+  int rows_nslab = 0;
+  if (h->lin_win || h->lin_rows) {
     const int nwg = (h->flat_chunks + LINF_WAVES - 1) / LINF_WAVES;
-    lin_wincam.assign((size_t)nwg * LINW_WIN, -1);
+    if (h->lin_win) lin_wincam.assign((size_t)nwg * LINW_WIN, -1);
     std::vector<int> idx;
     for (int wg = 0; wg < nwg; ++wg) {
-      int* win = lin_wincam.data() + (size_t)wg * LINW_WIN;
+      int* win = h->lin_win ? lin_wincam.data() + (size_t)wg * LINW_WIN : nullptr;
       int nwin = 0;
       for (int c = wg * LINF_WAVES; c < std::min(h->flat_chunks, (wg + 1) * LINF_WAVES); ++c) {
         const int kb = lin_k[c], ke = lin_k[c + 1];
@@ -1397,9 +1449,11 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
           if (p2 == 0 || o_cam[idx[p2]] != o_cam[idx[p2 - 1]]) {
             const int cam = o_cam[idx[p2]];
             int slot = -1;
-            for (int s2 = 0; s2 < nwin; ++s2)
-              if (win[s2] == cam) slot = s2;
-            if (slot < 0 && nwin < LINW_WIN) { slot = nwin; win[nwin++] = cam; }
+            if (win) {
+              for (int s2 = 0; s2 < nwin; ++s2)
+                if (win[s2] == cam) slot = s2;
+              if (slot < 0 && nwin < LINW_WIN) { slot = nwin; win[nwin++] = cam; }
+            }
             lin_gbeg.push_back((int)p2); lin_gcam.push_back(cam); lin_gslot.push_back(slot);
           }
         }
@@ -1407,6 +1461,30 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
         lin_gptr.push_back((int)lin_gbeg.size());
       }
     }
+  }
+  if (h->lin_rows) {
+    // inverted index camera -> rows of d.Urows (= entries of the group tables), ascending, cut into `rows_nslab` segments
+    // per camera: a wave of the fold sums one segment (fold_u_rows), the gather sums the segments
+    std::vector<int> per_cam(C + 1, 0);
+    for (int cam : lin_gcam)
+      if (cam >= 0) per_cam[cam + 1]++;
+    int max_rows = 0;
+    for (int c = 0; c < C; ++c) { max_rows = std::max(max_rows, per_cam[c + 1]); per_cam[c + 1] += per_cam[c]; }
+    rows_nslab = std::max(1, std::min(64, (max_rows + 23) / 24));
+    if (rows_nslab > 1) rows_nslab = (rows_nslab + 3) & ~3;
+    rows_nslab = env_int("BA_NSLAB_U", rows_nslab);
+    ucr_row.resize(per_cam[C]);
+    {
+      std::vector<int> fill(per_cam.begin(), per_cam.end() - 1);
+      for (size_t t = 0; t < lin_gcam.size(); ++t)
+        if (lin_gcam[t] >= 0) ucr_row[fill[lin_gcam[t]]++] = (int)t;
+    }
+    ucr_ptr.assign((size_t)C * rows_nslab + 1, 0);
+    for (int c = 0; c < C; ++c) {
+      const long cnt = per_cam[c + 1] - per_cam[c];
+      for (int s2 = 0; s2 < rows_nslab; ++s2) ucr_ptr[(size_t)c * rows_nslab + s2] = per_cam[c] + (int)(cnt * s2 / rows_nslab);
+    }
+    ucr_ptr[(size_t)C * rows_nslab] = per_cam[C];
   }
   // ---- k_schur_staged tables: chunks (consecutive landmarks, <= SCH_CAP observations, <= SCH_MAXLM
   // landmarks), the steps at which a wave must write its accumulators out (some lane's camera pair
@@ -1515,6 +1593,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
     h->d.nslab_u = env_int("BA_NSLAB_U", (int)std::min<size_t>(32, std::max<size_t>(1, ((size_t)8 << 20) / u_bytes)));
     h->d.nslab_s = env_int("BA_NSLAB_S", (int)std::min<size_t>(16, std::max<size_t>(1, ((size_t)32 << 20) / s_bytes)));
     if (h->schur_cpb > 0) h->d.nslab_s = 0;  // the staged path writes contribution rows instead
+    if (h->lin_rows) h->d.nslab_u = rows_nslab;  // the "slabs" are the segment sums of fold_u_rows
     h->d.s_slab_stride = (long)nu * 36 + 6L * Cf;
   }
   // one-workgroup reduced solve for small camera systems (S in registers, vectors + preconditioner +
@@ -1906,6 +1985,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
       (rc = dev_upload(h, &d.lin_perm, lin_perm)) || (rc = dev_upload(h, &d.lin_gptr, lin_gptr)) ||
       (rc = dev_upload(h, &d.lin_gbeg, lin_gbeg)) || (rc = dev_upload(h, &d.lin_gcam, lin_gcam)) ||
       (rc = dev_upload(h, &d.lin_gslot, lin_gslot)) || (rc = dev_upload(h, &d.lin_wincam, lin_wincam)) ||
+      (rc = dev_upload(h, &d.ucr_ptr, ucr_ptr)) || (rc = dev_upload(h, &d.ucr_row, ucr_row)) ||
       (rc = dev_upload(h, &d.sch_lm, sch_lm)) || (rc = dev_upload(h, &d.sch_k, sch_k)) ||
       (rc = dev_upload(h, &d.sch_flush, sch_flush)) || (rc = dev_upload(h, &d.sch_blk_row, sch_blk_row)) ||
       (rc = dev_upload(h, &d.ctr_ptr, ctr_ptr)) || (rc = dev_upload(h, &d.ctr_row, ctr_row)) ||
@@ -1913,6 +1993,12 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
     return rc;
   d.W = nullptr;
   if (!h->matrix_free && (rc = dev_alloc(h, &d.W, (size_t)W_ROWS * n))) return rc;
+  d.n_urows = h->lin_rows ? (long)lin_gcam.size() : 0;
+  d.n_bs_blocks = h->flat_chunks > 0 ? grid_for(h->flat_chunks, 4) : 0;
+  d.n_pose_blocks = grid_for(C);
+  if ((rc = dev_alloc(h, &d.Urows, (size_t)27 * d.n_urows)) || (rc = dev_alloc(h, &d.lin_part, (size_t)4 * h->flat_chunks)) ||
+      (rc = dev_alloc(h, &d.bs_part, (size_t)8 * d.n_bs_blocks)) || (rc = dev_alloc(h, &d.pose_part, (size_t)5 * d.n_pose_blocks)))
+    return rc;
   if ((rc = dev_alloc(h, &d.V, (size_t)6 * L)) ||
       (rc = dev_alloc(h, &d.gp, (size_t)3 * L)) || (rc = dev_alloc(h, &d.zmin, (size_t)L)) ||
       (rc = dev_alloc(h, &d.Ugc_part, (size_t)27 * C)) ||
@@ -2115,6 +2201,7 @@ int ba_evaluate(ba_handle* h, const double* poses, const double* points, double*
   if (!h->has_problem) return fail(h, BA_ERR_STATE, "evaluate before set_problem");
   if (!poses || !points) return fail(h, BA_ERR_INVALID, "null poses/points");
   HIP_TRY(h, hipSetDevice(h->device));
+  begin_launches(h);
   int rc = stage_state(h, poses, points, h->d.poses_buf[1], h->d.pts_buf[1]);
   if (rc) return rc;
   h->has_estimate = false;  // the trial buffers were clobbered
@@ -2141,6 +2228,7 @@ int ba_triangulate(ba_handle* h, const double* poses, int32_t refine_iters, doub
   if (!poses || !points) return fail(h, BA_ERR_INVALID, "null poses/points");
   if (refine_iters < 0 || !std::isfinite(min_depth)) return fail(h, BA_ERR_INVALID, "refine_iters < 0 or min_depth not finite");
   HIP_TRY(h, hipSetDevice(h->device));
+  begin_launches(h);
   // poses as in stage_state (every pose is data here: normalise all quaternions)
   double* sp = h->stage;
   for (int c = 0; c < h->C; ++c) {
@@ -2214,6 +2302,7 @@ int ba_jacobian_blocks(ba_handle* h, const double* poses, const double* points, 
   if (!h->has_problem) return fail(h, BA_ERR_STATE, "jacobian_blocks before set_problem");
   if (!poses || !points || !Jc || !Jp) return fail(h, BA_ERR_INVALID, "null argument");
   HIP_TRY(h, hipSetDevice(h->device));
+  begin_launches(h);
   int rc = stage_state(h, poses, points, h->d.poses_buf[1], h->d.pts_buf[1]);
   if (rc) return rc;
   h->has_estimate = false;
@@ -2236,6 +2325,7 @@ int ba_debug_linearization(ba_handle* h, const double* poses, const double* poin
   if (!h->has_problem) return fail(h, BA_ERR_STATE, "debug_linearization before set_problem");
   if (!poses || !points) return fail(h, BA_ERR_INVALID, "null poses/points");
   HIP_TRY(h, hipSetDevice(h->device));
+  begin_launches(h);
   double* P0 = h->d.poses_buf[0];
   double* X0 = h->d.pts_buf[0];
   double* P1 = h->d.poses_buf[1];
@@ -2385,8 +2475,24 @@ int ba_evaluate_static(int32_t device, int32_t C, int32_t L, int32_t n, const in
   }
   for (size_t i = 0; i < (size_t)3 * L; ++i)
     if (!std::isfinite(points[i])) return bad(BA_ERR_INVALID, "landmark %d has a non-finite coordinate", (int)(i / 3));
-  // poses exactly as stage_state prepares them for ba_evaluate: pose 0 is the fixed one
-  double sp[7 * ST_MAX_CAMS];
+#define ST_TRY(expr)                                                                                      \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess) {                                                                               \
+      (void)hipGetLastError();                                                                            \
+      return bad(BA_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));                           \
+    }                                                                                                     \
+  } while (0)
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return bad(BA_ERR_DEVICE, "no HIP device (there is no CPU fallback)");
+  int caller_device = 0;
+  ST_TRY(hipGetDevice(&caller_device));
+  if (device < 0) device = caller_device;
+  if (device >= ndev || device >= ST_MAX_DEVICES) return bad(BA_ERR_INVALID, "device %d does not exist", device);
+  std::lock_guard<std::mutex> lock(static_scratch_mutex);
+  // poses exactly as stage_state prepares them for ba_evaluate: pose 0 is the fixed one (staged in a host array that
+  // the lock above protects: 56 KB are too much for a caller's stack)
+  static double sp[7 * ST_MAX_CAMS];
   for (int c = 0; c < C; ++c) {
     const double* p = poses + 7 * c;
     for (int i = 0; i < 7; ++i)
@@ -2397,17 +2503,16 @@ int ba_evaluate_static(int32_t device, int32_t C, int32_t L, int32_t n, const in
     for (int i = 0; i < 3; ++i) sp[7 * c + i] = p[i];
     for (int i = 3; i < 7; ++i) sp[7 * c + i] = renorm ? p[i] / nq : p[i];
   }
-#define ST_TRY(expr)                                                                                      \
-  do {                                                                                                    \
-    hipError_t e_ = (expr);                                                                               \
-    if (e_ != hipSuccess) return bad(BA_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));       \
-  } while (0)
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return bad(BA_ERR_DEVICE, "no HIP device (there is no CPU fallback)");
-  if (device < 0) ST_TRY(hipGetDevice(&device));
-  if (device >= ndev || device >= ST_MAX_DEVICES) return bad(BA_ERR_INVALID, "device %d does not exist", device);
-  std::lock_guard<std::mutex> lock(static_scratch_mutex);
-  ST_TRY(hipSetDevice(device));
+  // the caller's current device is put back on every way out
+  struct DeviceGuard {
+    int prev, cur;
+    ~DeviceGuard() { if (cur != prev) (void)hipSetDevice(prev); }
+  } guard{caller_device, caller_device};
+  if (device != caller_device) {
+    ST_TRY(hipSetDevice(device));
+    guard.cur = device;
+  }
+  (void)hipGetLastError();  // an error left by an earlier call on this thread is not a refused launch of this one
   if (!static_scratch_ptr[device]) {  // once per device, with that device current: the address of ITS copy
     double* ptr = nullptr;
     ST_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));

@@ -89,6 +89,7 @@ _SIGNATURES = {
     "ba_set_kernel_timing": (C.c_int, [_P, C.c_int32]),
     "ba_comm_unique_id": (C.c_int, [C.c_char_p]),
     "ba_comm_init": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_char_p]),
+    "ba_comm_info": (C.c_int, [_P, _I, _I]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -226,6 +227,12 @@ class Solver:
         if len(unique_id) != 128:
             raise ValidationError("unique_id must be the 128 bytes of comm_unique_id()")
         self._check(self._lib.ba_comm_init(self._h, rank, world, unique_id))
+
+    def comm_info(self):
+        """(rank, world) as the communicator itself reports them (ba_comm_info); (0, 1) without one."""
+        r, w = C.c_int32(), C.c_int32()
+        self._check(self._lib.ba_comm_info(self._h, C.byref(r), C.byref(w)))
+        return r.value, w.value
 
     # -- problem
     def set_problem(self, n_cams, n_pts, obs_cam, obs_pt, obs_uv, intr, fixed=None):
