@@ -19,6 +19,8 @@ reduced camera system is all-reduced (DESIGN.md "Multi-GPU").  Rank 0 prints ONE
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -126,6 +128,9 @@ def run_workload(args, name, steps, warmup, dist, rank, world, local_rank, kerne
         uid = [_native.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         solver.comm_init(rank, world, uid[0])
+        comm_rank, comm_world = solver.comm_info()  # what RCCL itself reports (ncclCommUserRank / ncclCommCount)
+        if (comm_rank, comm_world) != (rank, world):
+            raise RuntimeError(f"communicator reports rank {comm_rank} of {comm_world}, the launcher said {rank} of {world}")
         sh, _ = sharding.shard_arrays(scene["obs_cam"], scene["obs_pt"], scene["obs_uv"], scene["points_guess"],
                                       rank, world)
         solver.set_problem(C, len(sh["points"]), sh["obs_cam"], sh["obs_pt"], sh["obs_uv"], scene["intr"])
@@ -136,6 +141,7 @@ def run_workload(args, name, steps, warmup, dist, rank, world, local_rank, kerne
         solver.upload_guess(scene["poses_guess"], scene["points_guess"])
         nobs, L_local = len(scene["obs_cam"]), L
     info = solver.problem_info()
+    n_gpus = solver.comm_info()[1]
 
     def barrier():
         # solve_resident() returns after the solver's stream is idle, so the device is quiet here; the
@@ -239,9 +245,44 @@ def run_workload(args, name, steps, warmup, dist, rank, world, local_rank, kerne
         "time_to_converge_ms": rep["solve_ms"], "lm_iterations": rep["iterations"], "lm_accepted": rep["accepted"],
         "pcg_iterations": rep["pcg_iters"], "final_cost": rep["cost"], "status": rep["status_name"],
         "rms_reproj_px": rep["rms_reproj"], "setup_ms": rep["setup_ms"], "bad_pivots": rep["bad_pivots"],
-        "roofline": roofline,
+        "roofline": roofline, "n_gpus": n_gpus,
     }
+    if dist is not None:
+        pids = [None] * world
+        dist.all_gather_object(pids, os.getpid())
+        out["rank_pids"] = pids
     return out, scene, rep
+
+
+def spawn_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` outside a launcher: start N rank processes of this script, one per GPU (fresh
+    children, started before this process has touched HIP; this process never does), with the rendezvous variables
+    that torch.distributed.run would set, pass rank 0's JSON line through and return non-zero if any rank failed."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=120))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(-9)
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: rank processes failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
 
 
 def main():
@@ -256,26 +297,55 @@ def main():
     ap.add_argument("--lm-check-every", type=int, default=None, help="override ba_options.lm_check_every")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--max-iters", type=int, default=None, help="cap the LM iterations of a solve (profiling passes only)")
+    ap.add_argument("--control-plane-only", action="store_true",
+                    help="rehearsal of the launch path without a GPU: ranks rendezvous (gloo), report themselves and exit")
     args = ap.parse_args()
     if args.workload is None:
         args.workload = "cfg3" if args.scaling == "strong" else "cfg2"
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    # --gpus N is what decides the number of GPUs.  Under a launcher (torch.distributed.run sets WORLD_SIZE) the two
+    # must agree; without one, N > 1 starts the N rank processes itself.  A mismatch is an error, never a silent
+    # one-GPU run that reports itself as N.
+    if "WORLD_SIZE" in os.environ:
+        if int(os.environ["WORLD_SIZE"]) != args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks",
+                  file=sys.stderr)
+            sys.exit(2)
+    elif args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if "RANK" in os.environ and "MASTER_ADDR" in os.environ:
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
         # control plane only (id exchange, barriers, max over ranks of the elapsed time): gloo on the CPU.
         # The data path is the solver's own RCCL communicator (ba_comm_init), one rank per GPU.
         import torch.distributed as dist
         dist.init_process_group("gloo")
+        if dist.get_world_size() != args.gpus:
+            print(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}", file=sys.stderr)
+            sys.exit(2)
+    if args.control_plane_only:
+        pids = [None] * world
+        if dist is not None:
+            dist.all_gather_object(pids, os.getpid())
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            pids = [os.getpid()]
+        if rank == 0:
+            print(json.dumps({"control_plane_only": True, "n_ranks": world, "rank_pids": pids, "n_gpus": None}))
+        return
 
     cap = {} if args.max_iters is None else {"max_iters": args.max_iters}
     res, scene, rep = run_workload(args, args.workload, args.steps, args.warmup, dist, rank, world, local_rank,
                                    kernel_events=not args.no_kernel_events, solver_opts=cap)
     if rank == 0:
         out = {"metric": "observations/sec per LM iteration", "value": res.pop("value"),
-               "unit": "observations*iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "unit": "observations*iterations/s", "n_gpus": res.pop("n_gpus"), "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True, "scaling": args.scaling,
                "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
         out.update(res)
@@ -288,6 +358,7 @@ def main():
                 leg, _, _ = run_workload(args, name, steps, 1 if name == "cfg3" else 0, None, 0, 1, local_rank,
                                          kernel_events=not args.no_kernel_events, solver_opts=cap)
                 leg["steps"] = steps
+                leg.pop("n_gpus", None)
                 leg["unit"] = "observations*iterations/s"
                 key = "roofline_large" if name == "cfg3" else "config4"
                 if name == "cfg3":  # the judge-facing shape: a roofline object, with the run it came from beside it

@@ -414,6 +414,7 @@ def test_residual_function_callback_paths(golden):
     entry point that allocates nothing, a problem beyond its limits through one cached handle; both equal the
     reference's recorded residuals / the oracle (1e-9 px)."""
     from src.bundle_adjustment import BundleAdjustment
+    BundleAdjustment.clear_residual_cache()  # (whatever an earlier test left)
     g = golden("noisy_10x300")
     feats, pose0, cam, guesses, lms = scenes.to_containers(scenes.noisy_scene(10, 300))
     n_poses = len(guesses)
@@ -431,3 +432,41 @@ def test_residual_function_callback_paths(golden):
             np.testing.assert_allclose(r, ref, rtol=0, atol=1e-9)
             first = BundleAdjustment._residual_solver[1]
     assert BundleAdjustment._residual_solver[1] is first  # one handle for the three calls
+    BundleAdjustment.clear_residual_cache()
+    assert BundleAdjustment._residual_solver is None and first._h is None
+
+
+def test_stale_hip_error_is_not_taken_for_a_failed_launch():
+    """HIP's "last error" is per host thread and sticky.  An error left behind by an earlier call on the thread (here:
+    a hipMalloc that cannot be satisfied, made straight through the runtime) must not make the next healthy solve /
+    evaluate / static evaluate report 'a kernel launch failed'."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    sc = scenes.noisy_scene(6, 120)
+    C, L = len(sc["poses_guess"]), len(sc["points_guess"])
+
+    def poison():
+        p = ctypes.c_void_p()
+        rc = hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(1 << 60))
+        assert rc != 0  # out of memory: the runtime remembers it until somebody asks
+
+    with _native.Solver() as s:
+        s.set_problem(C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+        _, _, ref = s.solve(sc["poses_guess"], sc["points_guess"])
+        poison()
+        _, _, rep = s.solve(sc["poses_guess"], sc["points_guess"])
+        assert rep["cost"] == ref["cost"]
+        poison()
+        r, cost, _ = s.evaluate(sc["poses_guess"], sc["points_guess"])
+        poison()
+        s.jacobian_blocks(sc["poses_guess"], sc["points_guess"])
+        poison()
+        s.debug_linearization(sc["poses_guess"], sc["points_guess"], 1e-3)
+        poison()
+        s.triangulate(sc["poses_guess"])
+    poison()
+    r2, cost2, _ = _native.evaluate_static(C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"], sc["poses_guess"],
+                                           sc["points_guess"])
+    assert abs(cost2 - cost) <= 1e-12 * cost
+    dev = ctypes.c_int(-1)
+    assert hip.hipGetDevice(ctypes.byref(dev)) == 0 and dev.value == 0  # the static entry point leaves the caller's device current

@@ -56,3 +56,20 @@ def test_coarse_space_repeated_solves_are_independent(monkeypatch):
         assert r["iterations"] == reps[0]["iterations"]
         assert r["pcg_history"][:2] == reps[0]["pcg_history"][:2]
         assert abs(r["cost"] - reps[0]["cost"]) <= 1e-9 * reps[0]["cost"]
+
+
+def test_coarse_space_with_lm_check_every(monkeypatch):
+    """lm_check_every > 1 together with the coarse space: the build on the side stream rewrites an inverse that queued
+    solves of the same parity would read, so the driver polls every iteration whenever the coarse space is on (the
+    option is ignored, not raced): same solution as lm_check_every = 1, and the same from run to run."""
+    monkeypatch.setenv("BA_PCG_COARSE", "1")
+    sc = scenes.ring_scene(50, 2000, 10)
+    costs = []
+    for every in (1, 3, 3):
+        with _native.Solver(linear_solver=1, lm_check_every=every) as s:
+            s.set_problem(50, 2000, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+            _, _, rep = s.solve(sc["poses_guess"], sc["points_guess"])
+        assert rep["status"] in (1, 2, 3) and rep["bad_pivots"] == 0
+        costs.append((rep["cost"], rep["iterations"], tuple(rep["pcg_history"][:2])))
+    assert costs[1][1:] == costs[0][1:] and abs(costs[1][0] - costs[0][0]) <= 1e-9 * costs[0][0]
+    assert costs[2][1:] == costs[1][1:] and abs(costs[2][0] - costs[1][0]) <= 1e-9 * costs[1][0]

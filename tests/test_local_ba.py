@@ -53,6 +53,22 @@ def test_window_construction():
         build_windows(kfs, map_ids, window=1)
 
 
+def test_sliding_window_refuses_an_oversized_prior_before_solving():
+    """window 18, stride 2 passes the constructor (16 keyframes handed on per shift), but with 25 keyframes the last
+    window is aligned to the end of the list and shifts by ONE keyframe: 17 would go into the prior, one more than it
+    holds.  That must surface before any window is solved (no GPU is touched: the check runs on the window list)."""
+    from src.local_ba import SlidingWindowBundleAdjustment
+    sc = scenes.ring_scene(25, 100, 4)
+    kfs = _keyframes(sc, sc["poses_gt"])
+    assert [w.first for w in build_windows(kfs, sc["landmark_ids"], window=18, stride=2)] == [0, 2, 4, 6, 7]
+    sw = SlidingWindowBundleAdjustment(window=18, stride=2)
+    with pytest.raises(ValidationError, match="hands 17 keyframes"):
+        sw.optimize(kfs, sc["points_gt"], sc["landmark_ids"], K_MAT)
+    assert sw.last_reports == []
+    with pytest.raises(ValidationError):
+        SlidingWindowBundleAdjustment(window=19, stride=2)
+
+
 def test_window_prior_chart_matches_oracle():
     """The host-side chart of the sliding-window prior (src/local_ba.py: _chart, WindowPrior.energy) against the oracle's
     prior_chart / prior_terms: the same coordinates and the same energy, and d(retract(ref, delta)) == delta."""

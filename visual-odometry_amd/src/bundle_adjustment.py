@@ -14,6 +14,8 @@ Deliberate differences from the reference:
 * ``bundle_adjustment_sparsity`` returns the mask without printing it densely (:153).
 """
 
+import atexit
+import hashlib
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -90,16 +92,27 @@ class BundleAdjustment:
         # observations stay the same (ba_set_problem sorts and uploads them: once, not per call)
         if _native.fits_static(num_poses + 1, L, len(obs_cam)):
             return _native.evaluate_static(num_poses + 1, L, obs_cam, obs_pt, obs_uv, intr, poses, points)[0]
-        key = (num_poses + 1, L, hash(obs_cam.tobytes()), hash(obs_pt.tobytes()), hash(obs_uv.tobytes()),
-               hash(np.asarray(intr, dtype=np.float64).tobytes()))
+        # the key is a cryptographic digest of the observation arrays (Python's hash() of their bytes is 64 bits and
+        # salted per process: a collision would silently return the residuals of another problem)
+        dig = hashlib.blake2b(digest_size=32)
+        for a in (obs_cam, obs_pt, obs_uv, np.asarray(intr, dtype=np.float64)):
+            dig.update(np.ascontiguousarray(a).tobytes())
+        key = (num_poses + 1, L, len(obs_cam), dig.digest())
         cache = BundleAdjustment._residual_solver
         if cache is None or cache[0] != key:
-            if cache is not None:
-                cache[1].close()
+            BundleAdjustment.clear_residual_cache()
             s = _native.Solver()
             s.set_problem(num_poses + 1, L, obs_cam, obs_pt, obs_uv, intr)
             BundleAdjustment._residual_solver = cache = (key, s)
         return cache[1].evaluate(poses, points)[0]
+
+    @staticmethod
+    def clear_residual_cache() -> None:
+        """Close the GPU handle that residual_function keeps for problems beyond the static entry point's limits
+        (also registered with atexit, so that no handle is open when the interpreter shuts the HIP runtime down)."""
+        cache, BundleAdjustment._residual_solver = BundleAdjustment._residual_solver, None
+        if cache is not None:
+            cache[1].close()
 
     # ------------------------------------------------------------------ mask (reference :89-154)
     @staticmethod
@@ -161,3 +174,6 @@ class BundleAdjustment:
                 ImageFeatures(feats.get_timestamp(), feats.get_camera_id(), image_width, image_height,
                               Features2D(camera_model.project(pts_cam), feats.get_points_2d().get_ids())))
         return optimized_image_features, optimized_points3d, optimized_camera_poses
+
+
+atexit.register(BundleAdjustment.clear_residual_cache)

@@ -256,6 +256,13 @@ class SlidingWindowBundleAdjustment:
         points = np.array(points_3d, dtype=float).reshape(-1, 3)
         intr = LocalBundleAdjustment._intrinsics(camera_matrix) if intrinsics is None else np.asarray(intrinsics, dtype=float)
         wins = build_windows(keyframes, points_3d_ids, self.window, self.stride, self.min_views)
+        # the keyframes that a window hands on to the next one carry the prior: check every actual shift BEFORE anything
+        # is solved (the last window is aligned to the end of the list and may shift by fewer than `stride` keyframes)
+        for w, nxt in zip(wins, wins[1:]):
+            kept = int(np.sum(w.keyframes >= nxt.first))
+            if kept > _native.Solver.PRIOR_MAX_CAMS:
+                raise ValidationError(f"the window starting at keyframe {w.first} hands {kept} keyframes on to the next one; "
+                                      f"a prior holds at most {_native.Solver.PRIOR_MAX_CAMS}")
         poses = np.array([np.concatenate([k.pose.position, k.pose.quaternion]) for k in keyframes]).reshape(-1, 7)
         poses[:, 3:7] /= np.linalg.norm(poses[:, 3:7], axis=1, keepdims=True)
         frozen = np.zeros(len(points), bool)
