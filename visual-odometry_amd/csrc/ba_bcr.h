@@ -128,9 +128,60 @@ __device__ __forceinline__ void bcr_update_item(const double* a, const double* b
   for (int c = 0; c < 6; ++c) out[c] = o[c];
 }
 
+// Round 3: the factorisation of T out of REGISTERS, without a single barrier or LDS access inside its loop.  The blocked
+// version below walks m / 6 column blocks with two workgroup barriers, a redundant 6 x 6 factorisation per thread and
+// two LDS round trips each: 8.2 of the 16 us of a k_bcr_level launch at m = 30 (wall_clock64 cuts), and that launch is
+// the unit of the critical path of the whole reduced solve (log2 N of them in a row).  Here a lane holds one ROW of T:
+// every wave keeps the m rows of D in its lanes 0 .. m - 1 (all four waves factor D redundantly: the other SIMDs would
+// idle anyway) and a quarter of the 3 m + 1 rows below it in the lanes after them; column j of the factor reaches
+// the other lanes through v_readlane (a scalar operand of the multiply-adds), one column at a time:
+//     p = T[j][j];  T[.][j] *= 1 / sqrt(p);  T[.][c] -= T[.][j] T[c][j]  for c > j.
+// The chain is m steps of (reciprocal square root, a row of independent multiply-adds); fully unrolled, row arrays in
+// registers (m doubles per lane).  m <= 36: the 64 lanes of a wave must hold m + ceil((3 m + 1) / 4) rows.
+template <int M>
+__device__ __forceinline__ bool bcr_factor_T_regs(double* T, int ld, int tid) {
+  constexpr int EXTRA = 3 * M + 1, EPW = (EXTRA + 3) / 4;  // rows below D, and their share per wave
+  static_assert(M + EPW <= 64, "a wave holds the rows of D and its share of the rows below in its 64 lanes");
+  const int lane = tid & 63, wv = tid >> 6;
+  const int e = wv * EPW + (lane - M);                               // index of this lane's row among the rows below D
+  const bool mine = lane >= M && lane - M < EPW && e < EXTRA;        // it has one
+  const int rho = lane < M ? lane : (mine ? M + e : 0);               // the row of T in this lane (idle lanes: row 0, never written back)
+  double row[M];
+#pragma unroll
+  for (int c = 0; c < M; ++c) row[c] = T[rho * ld + c];
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    double p = readlane_f64(row[j], j);
+    if (!(p > 0.0)) { bad = true; p = 1.0; }
+    // 1 / sqrt(p): hardware estimate + two Newton steps (the chain of every column)
+    double inv = __builtin_amdgcn_rsq(p);
+    inv = inv * fma(-0.5 * p * inv, inv, 1.5);
+    inv = inv * fma(-0.5 * p * inv, inv, 1.5);
+    const double t = row[j] * inv;
+    row[j] = t;
+#pragma unroll
+    for (int c = j + 1; c < M; ++c) row[c] = fma(-t, readlane_f64(t, c), row[c]);  // lane c holds T[c][j] = L[c][j]
+  }
+  if (mine) {
+#pragma unroll
+    for (int c = 0; c < M; ++c) T[rho * ld + c] = row[c];
+  }
+  __syncthreads();
+  return bad;
+}
+
 // The block Cholesky of the tall matrix T = [D ; Ea ; Eb^T ; I ; r^T] ((4 m + 1) x m in LDS, row stride ld): see
 // k_bcr_factor.  Called by every thread of the workgroup after a barrier that made T visible; returns with a barrier.
 __device__ __forceinline__ bool bcr_factor_T(double* T, int m, int ld, int tid) {
+  switch (m) {  // (the rows below D come back in T; the rows of D themselves are not needed afterwards)
+    case 12: return bcr_factor_T_regs<12>(T, ld, tid);
+    case 18: return bcr_factor_T_regs<18>(T, ld, tid);
+    case 24: return bcr_factor_T_regs<24>(T, ld, tid);
+    case 30: return bcr_factor_T_regs<30>(T, ld, tid);
+    case 36: return bcr_factor_T_regs<36>(T, ld, tid);
+    default: break;
+  }
   const int nb = m / 6, R = 4 * m + 1;
   bool bad = false;
   for (int j = 0; j < nb; ++j) {
@@ -201,7 +252,9 @@ __device__ __forceinline__ void bcr_store_factors(double* __restrict__ B, const 
 __global__ __launch_bounds__(BCR_THREADS) void k_bcr_factor(double* __restrict__ B, BcrPlan plan, int level, const LmCtrl* ctrl,
                                                             double* __restrict__ badv) {
   extern __shared__ double lds[];
-  if (ctrl && ctrl->done) return;
+  // (the "solve is over" flag is requested with the first round of loads and looked at after it: a launch that follows
+  // termination still exits before its first store, and a live one does not pay a round trip of its own for the flag)
+  const int done = ctrl ? ctrl->done : 0;
   const BcrLevel lv = plan.lv[level];
   const int m = plan.m, ld = m + 1, mm = m * m;
   const int tid = threadIdx.x;
@@ -220,6 +273,7 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_factor(double* __restrict__
       if (e < mm) { vd[u] = Di[e]; va[u] = Ea[e]; vb[u] = Eb[e]; }
     }
     const double rv = tid < m ? B[lv.r + (long)i * m + tid] : 0.0;
+    if (done) return;
 #pragma unroll
     for (int u = 0; u < BCR_EPT; ++u) {
       const int e = tid + u * BCR_THREADS;
@@ -306,7 +360,7 @@ static_assert(BCR_THREADS == 256, "the tile schedule below assumes four waves");
 // symmetric: only its lower tiles are computed.
 __global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_update(double* __restrict__ B, BcrPlan plan, int level, const LmCtrl* ctrl) {
   extern __shared__ double lds[];
-  if (ctrl && ctrl->done) return;
+  const int done = ctrl ? ctrl->done : 0;  // looked at after the first round of loads (see k_bcr_factor)
   const BcrLevel lv = plan.lv[level], nx = plan.lv[level + 1];
   const int m = plan.m, ld = m + 1, mm = m * m;
   const int tid = threadIdx.x;
@@ -355,6 +409,7 @@ __global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_update(double* __restric
         de[p][q] = (wv + 4 * p < nlow && r < m && c < m) ? De[r * m + c] : 0.0;
       }
     }
+    if (done) return;
 #pragma unroll
     for (int u = 0; u < BCR_EPT; ++u) {
       const int w = tid + u * BCR_THREADS;
@@ -441,7 +496,7 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_backsolve(double* __restric
                                                                const LmCtrl* ctrl, double* __restrict__ dc) {
   __shared__ double sF[3 * BCR_MAX_M * (BCR_MAX_M + 1)];
   __shared__ double xa[BCR_MAX_M], xb[BCR_MAX_M], tt[BCR_MAX_M], part[4][BCR_MAX_M];
-  if (ctrl && ctrl->done) return;
+  const int done = ctrl ? ctrl->done : 0;  // looked at after the round of loads (see k_bcr_factor)
   const BcrLevel lv = plan.lv[level];
   const int m = plan.m, ld = m + 1, mm = m * m, tid = threadIdx.x;
   const int q = blockIdx.x, n = lv.n;
@@ -468,6 +523,7 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_backsolve(double* __restric
       vb = X[ob * m + tid];
       vy = B[lv.y + (long)q * m + tid];
     }
+    if (done) return;
 #pragma unroll
     for (int u = 0; u < BCR_EPT; ++u) {
       const int w = tid + u * BCR_THREADS;
@@ -512,7 +568,7 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_backsolve(double* __restric
 __global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_level(double* __restrict__ B, BcrPlan plan, int level, const LmCtrl* ctrl,
                                                            double* __restrict__ badv) {
   extern __shared__ double lds[];
-  if (ctrl && ctrl->done) return;
+  const int done = ctrl ? ctrl->done : 0;  // looked at after the first round of loads (see k_bcr_factor)
   const BcrLevel lv = plan.lv[level], nx = plan.lv[level + 1];
   const int m = plan.m, ld = m + 1, mm = m * m;
   const int tid = threadIdx.x;
@@ -564,6 +620,7 @@ __global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_level(double* __restrict
         de[p][q] = (wv + 4 * p < nlow && r < m && c < m) ? De[r * m + c] : 0.0;
       }
     }
+    if (done) return;
 #pragma unroll
     for (int u = 0; u < BCR_EPT; ++u) {
       const int w = tid + u * BCR_THREADS;
@@ -671,6 +728,55 @@ __global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_level(double* __restrict
   if (bad && tid == 0) atomic_add_f64(badv, 1.0);
 }
 
+// The dense tail system out of registers (see bcr_factor_T_regs): lane r of wave 0 holds row r of the lower triangle
+// (row ND: the right-hand side), ND columns; after the ND elimination steps the rows go back to LDS, every lane picks
+// up a COLUMN of L and the backward sweep x = L^-T y runs as ND steps of (one v_readlane, one multiply-add per lane).
+// Returns after a barrier with x in xs[0 .. ND).
+template <int ND>
+__device__ __forceinline__ bool bcr_tail_regs(double* T, int ld, double* xs, int tid) {
+  static_assert(ND + 1 <= 64, "one row per lane");
+  bool bad = false;
+  if (tid < 64) {
+    const int lane = tid, rho = lane <= ND ? lane : 0;
+    double row[ND];
+#pragma unroll
+    for (int c = 0; c < ND; ++c) row[c] = T[rho * ld + c];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+      double p = readlane_f64(row[j], j);
+      if (!(p > 0.0)) { bad = true; p = 1.0; }
+      double inv = __builtin_amdgcn_rsq(p);
+      inv = inv * fma(-0.5 * p * inv, inv, 1.5);
+      inv = inv * fma(-0.5 * p * inv, inv, 1.5);
+      const double t = row[j] * inv;
+      row[j] = t;
+#pragma unroll
+      for (int c = j + 1; c < ND; ++c) row[c] = fma(-t, readlane_f64(t, c), row[c]);
+    }
+    // rows back to LDS (ld is odd: conflict-free), then lane j takes column j of L and y_j
+    if (lane <= ND) {
+#pragma unroll
+      for (int c = 0; c < ND; ++c) T[rho * ld + c] = row[c];
+    }
+    __builtin_amdgcn_wave_barrier();  // one wave: the LDS serves its accesses in order
+    const int col = lane < ND ? lane : 0;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) row[i] = T[i * ld + col];  // L[i][col] (i >= col; the rest is never used)
+    double y = T[ND * ld + col];
+    const double dinv = fast_rcp(T[col * ld + col]);
+    double x = 0.0;
+#pragma unroll
+    for (int i = ND - 1; i >= 0; --i) {
+      const double xi = readlane_f64(y * dinv, i);  // x_i = y_i / L_ii
+      x = lane == i ? xi : x;
+      y = fma(-row[i], xi, y);                       // y_j -= L[i][j] x_i for the columns j < i (later ones: consumed)
+    }
+    if (lane < ND) xs[lane] = x;
+  }
+  __syncthreads();
+  return bad;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_bcr_tail: the last n <= max(2, BCR_TAIL_ROWS / m) blocks (level `plan.n_levels`), one workgroup: the cyclic block
 // tridiagonal system is laid out as ONE dense symmetric matrix of Nd = n m rows in LDS, with the right-hand side as row
@@ -746,56 +852,65 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_tail(double* __restrict__ B
   }
   __syncthreads();
   bool bad = false;
-  for (int j = 0; j < nb; ++j) {
-    const int c0 = 6 * j;
-    double Li[36];
-    if (!chol6_inverse_ld(T + c0 * ld + c0, ld, Li)) bad = true;
-    double li_mine = 0.0;  // Li[tid] by a static select: a dynamic index would put Li in scratch memory
-#pragma unroll
-    for (int e = 0; e < 36; ++e) li_mine = (e == tid) ? Li[e] : li_mine;
-    if (tid < 36) sLi[j * 36 + tid] = li_mine;
-    for (int rho = c0 + 6 + tid; rho < R; rho += BCR_THREADS) {
-      double* row = T + rho * ld + c0;
-      double x[6], o[6];
-#pragma unroll
-      for (int t = 0; t < 6; ++t) x[t] = row[t];
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        double s = 0.0;
-#pragma unroll
-        for (int t = 0; t <= c; ++t) s += x[t] * Li[6 * c + t];
-        o[c] = s;
-      }
-#pragma unroll
-      for (int c = 0; c < 6; ++c) row[c] = o[c];
-    }
-    __syncthreads();
-    const int nbc = nb - 1 - j, rows = R - (c0 + 6);
-    for (int w = tid; w < rows * nbc; w += BCR_THREADS) {
-      const int rr = w / nbc, rho = c0 + 6 + rr, kb = j + 1 + (w - rr * nbc), cb = 6 * kb;
-      if (rho < cb) continue;  // lower triangle (the right-hand-side row is below everything)
-      bcr_update_item(T + rho * ld + c0, T + cb * ld + c0, T + rho * ld + cb, ld);
-    }
-    __syncthreads();
+  bool in_regs = true;
+  switch (Nd) {  // a row of the dense system per lane of ONE wave (Nd + 1 <= 64 rows): bcr_tail_regs
+    case 48: bad = bcr_tail_regs<48>(T, ld, xs, tid); break;
+    case 54: bad = bcr_tail_regs<54>(T, ld, xs, tid); break;
+    case 60: bad = bcr_tail_regs<60>(T, ld, xs, tid); break;
+    default: in_regs = false; break;
   }
-  // backward sweep on y (row Nd of T)
-  double* y = T + (long)Nd * ld;
-  for (int j = nb - 1; j >= 0; --j) {
-    const int c0 = 6 * j;
-    if (tid < 6) {  // x_j = L_jj^-T y_j:  x[c] = sum_{t >= c} Li[t][c] y[t]
-      double x = 0.0;
-#pragma unroll
-      for (int t = 0; t < 6; ++t) x += (t >= tid) ? sLi[j * 36 + 6 * t + tid] * y[c0 + t] : 0.0;
-      xs[c0 + tid] = x;
+  if (!in_regs) {
+    for (int j = 0; j < nb; ++j) {
+      const int c0 = 6 * j;
+      double Li[36];
+      if (!chol6_inverse_ld(T + c0 * ld + c0, ld, Li)) bad = true;
+      double li_mine = 0.0;  // Li[tid] by a static select: a dynamic index would put Li in scratch memory
+  #pragma unroll
+      for (int e = 0; e < 36; ++e) li_mine = (e == tid) ? Li[e] : li_mine;
+      if (tid < 36) sLi[j * 36 + tid] = li_mine;
+      for (int rho = c0 + 6 + tid; rho < R; rho += BCR_THREADS) {
+        double* row = T + rho * ld + c0;
+        double x[6], o[6];
+  #pragma unroll
+        for (int t = 0; t < 6; ++t) x[t] = row[t];
+  #pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          double s = 0.0;
+  #pragma unroll
+          for (int t = 0; t <= c; ++t) s += x[t] * Li[6 * c + t];
+          o[c] = s;
+        }
+  #pragma unroll
+        for (int c = 0; c < 6; ++c) row[c] = o[c];
+      }
+      __syncthreads();
+      const int nbc = nb - 1 - j, rows = R - (c0 + 6);
+      for (int w = tid; w < rows * nbc; w += BCR_THREADS) {
+        const int rr = w / nbc, rho = c0 + 6 + rr, kb = j + 1 + (w - rr * nbc), cb = 6 * kb;
+        if (rho < cb) continue;  // lower triangle (the right-hand-side row is below everything)
+        bcr_update_item(T + rho * ld + c0, T + cb * ld + c0, T + rho * ld + cb, ld);
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    for (int rho = tid; rho < c0; rho += BCR_THREADS) {  // y_rho -= sum_c L[c0 + c][rho] x_j[c]
-      double s = 0.0;
-#pragma unroll
-      for (int c = 0; c < 6; ++c) s += T[(c0 + c) * ld + rho] * xs[c0 + c];
-      y[rho] -= s;
+    // backward sweep on y (row Nd of T)
+    double* y = T + (long)Nd * ld;
+    for (int j = nb - 1; j >= 0; --j) {
+      const int c0 = 6 * j;
+      if (tid < 6) {  // x_j = L_jj^-T y_j:  x[c] = sum_{t >= c} Li[t][c] y[t]
+        double x = 0.0;
+  #pragma unroll
+        for (int t = 0; t < 6; ++t) x += (t >= tid) ? sLi[j * 36 + 6 * t + tid] * y[c0 + t] : 0.0;
+        xs[c0 + tid] = x;
+      }
+      __syncthreads();
+      for (int rho = tid; rho < c0; rho += BCR_THREADS) {  // y_rho -= sum_c L[c0 + c][rho] x_j[c]
+        double s = 0.0;
+  #pragma unroll
+        for (int c = 0; c < 6; ++c) s += T[(c0 + c) * ld + rho] * xs[c0 + c];
+        y[rho] -= s;
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   double* __restrict__ X = B + plan.X;
   for (int e = tid; e < Nd; e += BCR_THREADS) {
