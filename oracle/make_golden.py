@@ -282,6 +282,98 @@ def run_lean_restated(scene, pk):
     return out, res
 
 
+# ----------------------------------------------------------------------------- round 3: shapes that were oracle-only
+def packed_to_reference_scene(sc):
+    """A packed scene of the product's generator (visual-odometry_amd/scenes.py: plain arrays) as the positional
+    arguments of the reference's optimize(): the reference's own container classes around the same numbers."""
+    from src.feature_observation import Features2D
+    cam = PinHoleCamera(fx=float(sc["intr"][0]), fy=float(sc["intr"][1]), cx=float(sc["intr"][2]), cy=float(sc["intr"][3]))
+    C = len(sc["poses_gt"])
+    ids = np.asarray(sc["landmark_ids"])
+    stamps = sc.get("timestamps", np.arange(C, dtype=float))
+    feats = []
+    for c in range(C):
+        sel = sc["obs_cam"] == c
+        feats.append(ImageFeatures(float(stamps[c]), 0, 640, 480, Features2D(sc["obs_uv"][sel], ids[sc["obs_pt"][sel]])))
+    pg = sc["poses_guess"]
+    poses = [CameraPose(pg[c, :3].copy(), pg[c, 3:7].copy(), float(stamps[c])) for c in range(C)]
+    return cam, feats, poses, Landmarks3D(sc["points_guess"].copy(), ids)
+
+
+def run_reference_on_packed(sc, shipped: bool, polish_dense: bool):
+    """The reference on a scene of the product's generator.  shipped: BundleAdjustment.optimize itself
+    (bundle_adjustment.py:156-288, least_squares captured); else the lean path of SURVEY.md Appendix C (the reference's
+    residual_function + the reference's kwargs + a vectorised mask: optimize() prints the dense mask and cannot run at
+    this size).  Then the tight-tolerance minimum from the reference's result."""
+    cam, feats, poses, lm_guess = packed_to_reference_scene(sc)
+    n_poses = len(poses) - 1
+    args = (poses[0], n_poses, lm_guess.get_ids(), feats, cam)
+    x0 = np.concatenate([sc["poses_guess"][1:].reshape(-1), sc["points_guess"].reshape(-1)])
+    out = {"residual_at_x0": ref_ba.BundleAdjustment.residual_function(x0, *args)}
+    a = (sc["poses_guess"][0].copy(), n_poses, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+    assert np.abs(out["residual_at_x0"] - orc.residual_packed(x0, *a)).max() <= 1e-9
+    t0 = time.perf_counter()
+    if shipped:
+        captured = {}
+        real_lsq = ref_ba.least_squares
+
+        def spy(*aa, **kw):
+            captured["res"] = real_lsq(*aa, **kw)
+            return captured["res"]
+
+        ref_ba.least_squares = spy
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                ref_ba.BundleAdjustment().optimize(feats, poses[0], cam, poses[1:], lm_guess)
+        finally:
+            ref_ba.least_squares = real_lsq
+        res = captured["res"]
+    else:
+        mask = orc.sparsity_mask(n_poses, len(lm_guess.get_ids()), sc["obs_cam"], sc["obs_pt"])
+        res = ref_ba.least_squares(ref_ba.BundleAdjustment.residual_function, x0, jac_sparsity=mask, method="trf",
+                                   x_scale="jac", ftol=1e-6, xtol=1e-6, gtol=1e-6, max_nfev=2000, args=args)
+    out["ref_seconds"] = np.array(time.perf_counter() - t0)
+    out.update(x0=x0, ref_x=res.x, ref_cost=np.array(res.cost), ref_status=np.array(res.status), ref_nfev=np.array(res.nfev),
+               ref_njev=np.array(res.njev), ref_optimality=np.array(res.optimality))
+    t0 = time.perf_counter()
+    pol = orc.polish(res.x, *a, dense=polish_dense, max_nfev=300 if polish_dense else 400)
+    out.update(polished_cost=np.array(pol.cost), polished_x=pol.x, polished_status=np.array(pol.status),
+               polished_nfev=np.array(pol.nfev), polished_optimality=np.array(pol.optimality),
+               polished_by=np.array("scipy trf exact (dense)" if polish_dense else "scipy trf lsmr, analytic Jacobian, ftol 1e-14"),
+               polished_seconds=np.array(time.perf_counter() - t0))
+    return out
+
+
+def round3_fixtures(only):
+    """(a) four windows of BASELINE configs[4] (10 keyframes x 100 landmarks, all co-visible: the seeds that
+    tests/test_gpu_batched.py samples from its 1024-window batch) through the reference's optimize() + the dense exact
+    polish; (b) the 120-camera arc with the camera spacing of the 10 000-camera ring (configs[3]'s geometry, the scene
+    of tests/test_gpu_config4.py) through the lean scipy path + a tight-tolerance scipy run.  The scenes come from the
+    product's generator (plain numpy) and are stored whole: the tests feed the same numbers to the GPU."""
+    sys.path.insert(2, os.path.join(ROOT, "visual-odometry_amd"))
+    import scenes  # (its `from src.geometry import ...` resolves to the reference's module here: same formulas)
+    keys = ("intr", "obs_cam", "obs_pt", "obs_uv", "poses_guess", "points_guess", "poses_gt", "points_gt", "landmark_ids")
+    for seed in (0, 333, 700, 1023):
+        name = f"window_{seed}_10x100"
+        if only and name not in only and "windows" not in only:
+            continue
+        t0 = time.time()
+        sc = scenes.local_window_scene(seed, K=10, L=100)
+        out = run_reference_on_packed(sc, shipped=True, polish_dense=True)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **{k: sc[k] for k in keys}, **out)
+        print(f"{name}: ref cost {float(out['ref_cost']):.12g} status {int(out['ref_status'])} nfev {int(out['ref_nfev'])}  "
+              f"polished {float(out['polished_cost']):.12g} (status {int(out['polished_status'])})  ({time.time() - t0:.1f}s)", flush=True)
+    name = "arc_120x6000"
+    if not only or name in only:
+        t0 = time.time()
+        sc = scenes.ring_scene(120, 6000, 5, spacing_of=10000)
+        out = run_reference_on_packed(sc, shipped=False, polish_dense=False)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **{k: sc[k] for k in keys}, **out)
+        print(f"{name}: ref cost {float(out['ref_cost']):.12g} status {int(out['ref_status'])} nfev {int(out['ref_nfev'])} in "
+              f"{float(out['ref_seconds']):.0f}s  polished {float(out['polished_cost']):.12g} (status {int(out['polished_status'])}, "
+              f"nfev {int(out['polished_nfev'])}, {float(out['polished_seconds']):.0f}s)  ({time.time() - t0:.1f}s)", flush=True)
+
+
 def known_answers():
     """Outputs of the reference helpers on the inputs its own unit tests use
     (tests/test_camera.py:97-109, tests/test_camera_pose.py:120-177, tests/test_geometry.py:92-146)."""
@@ -377,6 +469,8 @@ def main():
     if not only or "known_answers" in only:
         np.savez_compressed(os.path.join(OUT, "known_answers.npz"), **known_answers(), **triangulation_known_answer())
         print("known_answers written")
+    if only & {"windows", "arc_120x6000"} or any(n.startswith("window_") for n in only):
+        round3_fixtures(only)
 
 
 if __name__ == "__main__":

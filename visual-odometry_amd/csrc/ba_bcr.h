@@ -28,7 +28,21 @@
 #include "ba_banded.h"
 #include "ba_dense.h"
 
+// -DBCR_CLOCKS: wall_clock64 cuts (10 ns ticks) inside the kernels of the chain, printed by one thread (a debug build,
+// tools/bcr_clocks.sh: never the library that ships)
+#ifdef BCR_CLOCKS
+#define BCR_CUT(i) do { if (threadIdx.x == 0) bcr_cut[i] = wall_clock64(); } while (0)
+#define BCR_CUTS_DECL long long bcr_cut[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define BCR_CUTS_PRINT(name, lvl, who) do { if (threadIdx.x == 0 && blockIdx.x == (who)) printf("%s level %d: %lld %lld %lld %lld %lld %lld (x10 ns)\n", name, lvl, bcr_cut[1] - bcr_cut[0], bcr_cut[2] - bcr_cut[1], bcr_cut[3] - bcr_cut[2], bcr_cut[4] - bcr_cut[3], bcr_cut[5] - bcr_cut[4], bcr_cut[6] - bcr_cut[5]); } while (0)
+#else
+#define BCR_CUT(i) do {} while (0)
+#define BCR_CUTS_DECL do {} while (0)
+#define BCR_CUTS_PRINT(name, lvl, who) do {} while (0)
+#endif
+
 constexpr int BCR_THREADS = 256;
+constexpr int BCR_BCAST_WAVE = 2 * 64;              // doubles per wave: two column buffers (bcr_reg_step)
+constexpr int BCR_BCAST = 4 * BCR_BCAST_WAVE + 2;   // the workgroup's share of LDS for them (+ 2: room to align to 16 bytes)
 constexpr int BCR_MAX_M = 48;      // 8 cameras per super-block
 constexpr int BCR_MAX_LEVELS = 24;
 constexpr int BCR_TAIL_ROWS = 64;   // the last max(2, BCR_TAIL_ROWS / m) blocks are solved densely by one workgroup (a step of its
@@ -39,6 +53,17 @@ struct BcrLevel {
   int n_elim;   // blocks eliminated here: the odd ones (n / 2); 0 at the tail level (lv[n_levels])
   long D, E, r;            // offsets (doubles) of D [n][m*m], E [n][m*m], r [n][m]
   long LiT, Fa, Fb, y;     // offsets of the factors of the eliminated blocks [n_elim][...]
+};
+
+// The top back-substitution levels that k_bcr_tail runs itself, after its dense solve (a wave per eliminated block, x of
+// the blocks involved in an LDS copy): a level of one to eight blocks is not worth a launch of its own.
+constexpr int BCR_TOP_MAX = 4;
+struct BcrTop {
+  int n;                     // levels folded in (0: none), highest level first
+  int xshift;                // the LDS copy of x is indexed by (level-0 block >> xshift): xshift = the lowest folded level
+  int nx;                    // its blocks (= blocks of the lowest folded level)
+  int level[BCR_TOP_MAX];
+  BcrLevel lv[BCR_TOP_MAX];
 };
 
 struct BcrPlan {
@@ -103,6 +128,9 @@ __device__ __forceinline__ bool chol6_inverse_ld(const double* A, int ld, double
 }
 
 constexpr int BCR_EPT = (BCR_MAX_M * BCR_MAX_M + BCR_THREADS - 1) / BCR_THREADS;  // entries of a block per thread
+// first 16-byte aligned double at or after p, both inside the 16-byte aligned dynamic LDS array `base` (index arithmetic
+// only: a cast through an integer would lose the LDS address space and turn every access into a flat one)
+__device__ __forceinline__ double* bcr_align16(double* base, double* p) { return base + (((p - base) + 1) & ~1L); }
 
 // One item of a trailing update: out[0..6) -= sum_t a[t] * b[c * ld + t].  a, b and out point into the same LDS array,
 // so the compiler must assume that a store to out changes b: every load is issued before the first store here (one
@@ -138,8 +166,94 @@ __device__ __forceinline__ void bcr_update_item(const double* a, const double* b
 //     p = T[j][j];  T[.][j] *= 1 / sqrt(p);  T[.][c] -= T[.][j] T[c][j]  for c > j.
 // The chain is m steps of (reciprocal square root, a row of independent multiply-adds); fully unrolled, row arrays in
 // registers (m doubles per lane).  m <= 36: the 64 lanes of a wave must hold m + ceil((3 m + 1) / 4) rows.
+// One elimination step of the register-resident factorisations below.  Column j - 1 of the factor (tp: this lane's
+// entry; the whole column sits in `prev`, an LDS buffer that the wave wrote in the step before) updates the columns
+// after j; column j gets its last update and its pivot chain.  The column reaches the other lanes in two ways: the ONE
+// entry on the critical path (L[j][j - 1], then the pivot itself) through v_readlane, everything else as 16-byte LDS
+// reads of a uniform address (a broadcast: two entries per instruction, issued beside the arithmetic and a whole step
+// ahead of their use), because four v_readlane / s_nop / v_fma instructions per entry made the loop issue-bound
+// (1.5 k instructions at ~5 cycles for the 24 columns of a level: 3.5 us measured; 15 us for the 48 of the tail).
+constexpr int BCR_GAPS = 8;  // places in the pivot chain of a column where updates of other columns are issued
+template <int M, int J>
+__device__ __forceinline__ void bcr_reg_step(double (&row)[M], double2 (&bc)[M / 2], double& tp, bool& bad,
+                                             double* __restrict__ cur, int lane) {
+  // bc: column J - 1 of the factor, two entries per element (entries 2 k and 2 k + 1), requested from LDS at the end of
+  // the step before; pairs from C0 / 2 on update the columns after J (the pair that starts at J holds the entry that
+  // went in through v_readlane)
+  constexpr int C0 = (J + 1) & ~1, K0 = C0 / 2, NP = J > 0 ? M / 2 - K0 : 0, PER = (NP + BCR_GAPS - 1) / BCR_GAPS;
+  auto updates = [&](int gap) {  // the gap-th share of the column updates (compile-time bounds after unrolling)
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int k = K0 + gap * PER + u;
+      if (k < M / 2) {
+        if (2 * k > J) row[2 * k] = fma(-tp, bc[k].x, row[2 * k]);
+        row[2 * k + 1] = fma(-tp, bc[k].y, row[2 * k + 1]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // The schedule is written out by hand, a fence after every link of the chain: left alone, the scheduler either sinks
+  // every update to where its column is needed (column j then waits for j dependent multiply-adds) or, inside one
+  // region per column, hoists the updates in front of the chain, where they wait for the LDS reads instead of hiding
+  // the chain's latencies.
+  // The chain of a column, as short as it gets: the pivot is row J's diagonal entry after its last update, formed from
+  // TWO independent v_readlane pairs (the entry before the update and L[J][J - 1]) instead of update -> v_readlane; a
+  // non-positive pivot is clamped with one v_max (no compare / select through the scalar unit) and counted off the
+  // chain; 1 / sqrt(p) is the hardware estimate and ONE third-order step (e = 1 - p y^2; y += y e (1/2 + 3/8 e): full
+  // fp64 from an estimate good to 2^-20 or better), five dependent operations instead of six.
+  double p = readlane_f64(row[J], J);
+  if constexpr (J > 0) {
+    const double s = readlane_f64(tp, J);
+    p = fma(-s, s, p);
+    row[J] = fma(-tp, s, row[J]);
+  }
+  if (!(p > 0.0)) bad = true;
+  p = fmax(p, 1e-300);
+  __builtin_amdgcn_sched_barrier(0);
+  double inv = __builtin_amdgcn_rsq(p);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (NP > 0) updates(0);
+  double a = p * inv;
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (NP > 0) updates(1);
+  const double e = fma(-a, inv, 1.0);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (NP > 0) updates(2);
+  a = fma(0.375, e, 0.5);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (NP > 0) updates(3);
+  a = a * e;
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (NP > 0) updates(4);
+  inv = fma(inv, a, inv);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (NP > 0) { updates(5); updates(6); }
+  const double t = row[J] * inv;
+  row[J] = t;
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (NP > 0) updates(7);  // (the last share: bc is about to be refilled with column J)
+  cur[lane] = t;  // column J: for the broadcast reads of the next step, issued right here
+  if constexpr (J + 1 < M) {
+    constexpr int K1 = ((J + 2) & ~1) / 2;
+    const double2* __restrict__ pv = reinterpret_cast<const double2*>(cur);
+#pragma unroll
+    for (int k = K1; k < M / 2; ++k) bc[k] = pv[k];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  tp = t;
+}
+template <int M, int J = 0>
+__device__ __forceinline__ void bcr_reg_steps(double (&row)[M], double2 (&bc)[M / 2], double& tp, bool& bad,
+                                              double* __restrict__ bcast, int lane) {
+  if constexpr (J < M) {
+    bcr_reg_step<M, J>(row, bc, tp, bad, bcast + (J & 1) * 64, lane);
+    bcr_reg_steps<M, J + 1>(row, bc, tp, bad, bcast, lane);
+  }
+}
+
 template <int M>
-__device__ __forceinline__ bool bcr_factor_T_regs(double* T, int ld, int tid) {
+__device__ __forceinline__ bool bcr_factor_T_regs(double* T, int ld, int tid, double* bcast) {
+  static_assert(M % 2 == 0, "the broadcast reads take the columns two at a time");
   constexpr int EXTRA = 3 * M + 1, EPW = (EXTRA + 3) / 4;  // rows below D, and their share per wave
   static_assert(M + EPW <= 64, "a wave holds the rows of D and its share of the rows below in its 64 lanes");
   const int lane = tid & 63, wv = tid >> 6;
@@ -150,19 +264,9 @@ __device__ __forceinline__ bool bcr_factor_T_regs(double* T, int ld, int tid) {
 #pragma unroll
   for (int c = 0; c < M; ++c) row[c] = T[rho * ld + c];
   bool bad = false;
-#pragma unroll
-  for (int j = 0; j < M; ++j) {
-    double p = readlane_f64(row[j], j);
-    if (!(p > 0.0)) { bad = true; p = 1.0; }
-    // 1 / sqrt(p): hardware estimate + two Newton steps (the chain of every column)
-    double inv = __builtin_amdgcn_rsq(p);
-    inv = inv * fma(-0.5 * p * inv, inv, 1.5);
-    inv = inv * fma(-0.5 * p * inv, inv, 1.5);
-    const double t = row[j] * inv;
-    row[j] = t;
-#pragma unroll
-    for (int c = j + 1; c < M; ++c) row[c] = fma(-t, readlane_f64(t, c), row[c]);  // lane c holds T[c][j] = L[c][j]
-  }
+  double tp = 0.0;
+  double2 bc[M / 2];
+  bcr_reg_steps<M>(row, bc, tp, bad, bcast + wv * BCR_BCAST_WAVE, lane);  // (every wave its own two column buffers)
   if (mine) {
 #pragma unroll
     for (int c = 0; c < M; ++c) T[rho * ld + c] = row[c];
@@ -173,13 +277,13 @@ __device__ __forceinline__ bool bcr_factor_T_regs(double* T, int ld, int tid) {
 
 // The block Cholesky of the tall matrix T = [D ; Ea ; Eb^T ; I ; r^T] ((4 m + 1) x m in LDS, row stride ld): see
 // k_bcr_factor.  Called by every thread of the workgroup after a barrier that made T visible; returns with a barrier.
-__device__ __forceinline__ bool bcr_factor_T(double* T, int m, int ld, int tid) {
+__device__ __forceinline__ bool bcr_factor_T(double* T, int m, int ld, int tid, double* bcast) {
   switch (m) {  // (the rows below D come back in T; the rows of D themselves are not needed afterwards)
-    case 12: return bcr_factor_T_regs<12>(T, ld, tid);
-    case 18: return bcr_factor_T_regs<18>(T, ld, tid);
-    case 24: return bcr_factor_T_regs<24>(T, ld, tid);
-    case 30: return bcr_factor_T_regs<30>(T, ld, tid);
-    case 36: return bcr_factor_T_regs<36>(T, ld, tid);
+    case 12: return bcr_factor_T_regs<12>(T, ld, tid, bcast);
+    case 18: return bcr_factor_T_regs<18>(T, ld, tid, bcast);
+    case 24: return bcr_factor_T_regs<24>(T, ld, tid, bcast);
+    case 30: return bcr_factor_T_regs<30>(T, ld, tid, bcast);
+    case 36: return bcr_factor_T_regs<36>(T, ld, tid, bcast);
     default: break;
   }
   const int nb = m / 6, R = 4 * m + 1;
@@ -233,7 +337,9 @@ __device__ __forceinline__ void bcr_store_factors(double* __restrict__ B, const 
     const int r = e / m, c = e - r * m;
     Fa[e] = T[(m + r) * ld + c];
     Fb[e] = T[(2 * m + r) * ld + c];
-    LiT[e] = c >= r ? T[(3 * m + r) * ld + c] : 0.0;
+    // L^-T goes out TRANSPOSED (entry [r][c] of the stored block is L^-T[c][r] = L^-1[r][c]): the back-substitution
+    // keeps row `lane` of L^-T in lane `lane`, and reads it with coalesced loads this way
+    LiT[e] = r >= c ? T[(3 * m + c) * ld + r] : 0.0;
   }
   if (tid < m) B[lv.y + (long)q * m + tid] = T[4 * m * ld + tid];
 }
@@ -249,14 +355,15 @@ __device__ __forceinline__ void bcr_store_factors(double* __restrict__ B, const 
 // multiply-adds): what is left below D_i is Fa = E_{i-1} L^-T, Fb = E_i^T L^-T, L^-T and y^T = (L^-1 r_i)^T.
 // All global loads are issued before the first use (one round trip, not one per loop iteration).
 // (Levels have n >= 3 blocks: smaller systems go to k_bcr_tail.)
-__global__ __launch_bounds__(BCR_THREADS) void k_bcr_factor(double* __restrict__ B, BcrPlan plan, int level, const LmCtrl* ctrl,
+__global__ __launch_bounds__(BCR_THREADS) void k_bcr_factor(double* __restrict__ B, BcrLevel lv, int m, const LmCtrl* ctrl,
                                                             double* __restrict__ badv) {
-  extern __shared__ double lds[];
+  extern __shared__ __align__(16) double lds[];
   // (the "solve is over" flag is requested with the first round of loads and looked at after it: a launch that follows
   // termination still exits before its first store, and a live one does not pay a round trip of its own for the flag)
   const int done = ctrl ? ctrl->done : 0;
-  const BcrLevel lv = plan.lv[level];
-  const int m = plan.m, ld = m + 1, mm = m * m;
+  // (the level's offsets arrive as kernel arguments, by value: indexing a plan structure in the argument block with
+  // the level number cost every launch of the chain a dependent scalar load before its first global load)
+  const int ld = m + 1, mm = m * m;
   const int tid = threadIdx.x;
   const int q = blockIdx.x;                    // q-th eliminated block
   const int i = 2 * q + 1;                     // its index at this level
@@ -288,7 +395,7 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_factor(double* __restrict__
     if (tid < m) T[4 * m * ld + tid] = rv;
   }
   __syncthreads();
-  const bool bad = bcr_factor_T(T, m, ld, tid);
+  const bool bad = bcr_factor_T(T, m, ld, tid, bcr_align16(lds, T + (4 * m + 1) * ld));
   bcr_store_factors(B, lv, q, T, m, ld, tid);
   if (bad && tid == 0) atomic_add_f64(badv, 1.0);
 }
@@ -358,11 +465,10 @@ static_assert(BCR_THREADS == 256, "the tile schedule below assumes four waves");
 // k_bcr_update: one workgroup per even block e of level l = block e / 2 of level l + 1 (formulas in the header).
 // The products run as 16 x 16 tiles on the fp64 matrix instruction (bcr_tile_xyt), a tile per wave and turn; D' is
 // symmetric: only its lower tiles are computed.
-__global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_update(double* __restrict__ B, BcrPlan plan, int level, const LmCtrl* ctrl) {
-  extern __shared__ double lds[];
+__global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_update(double* __restrict__ B, BcrLevel lv, BcrLevel nx, int m, const LmCtrl* ctrl) {
+  extern __shared__ __align__(16) double lds[];
   const int done = ctrl ? ctrl->done : 0;  // looked at after the first round of loads (see k_bcr_factor)
-  const BcrLevel lv = plan.lv[level], nx = plan.lv[level + 1];
-  const int m = plan.m, ld = m + 1, mm = m * m;
+  const int ld = m + 1, mm = m * m;
   const int tid = threadIdx.x;
   const int k = blockIdx.x, e = 2 * k, n = lv.n;
   // odd neighbours (indices into the factor arrays), -1: none
@@ -491,18 +597,19 @@ __global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_update(double* __restric
 // the even neighbours is already in X (indexed by the level-0 block: block i of level l is block i << l of level 0).
 // Also scatters x_i to the camera step dc ([Cf][6]; cam0[blk] = first free camera of a level-0 block, cnt[blk] its
 // camera count).  The three factor blocks come in with one round of loads.
-__global__ __launch_bounds__(BCR_THREADS) void k_bcr_backsolve(double* __restrict__ B, BcrPlan plan, int level,
+__global__ __launch_bounds__(BCR_THREADS) void k_bcr_backsolve(double* __restrict__ B, BcrLevel lv, int m, long Xoff, int level,
                                                                const int* __restrict__ cam0, const int* __restrict__ cnt,
                                                                const LmCtrl* ctrl, double* __restrict__ dc) {
   __shared__ double sF[3 * BCR_MAX_M * (BCR_MAX_M + 1)];
   __shared__ double xa[BCR_MAX_M], xb[BCR_MAX_M], tt[BCR_MAX_M], part[4][BCR_MAX_M];
+  BCR_CUTS_DECL;
+  BCR_CUT(0);
   const int done = ctrl ? ctrl->done : 0;  // looked at after the round of loads (see k_bcr_factor)
-  const BcrLevel lv = plan.lv[level];
-  const int m = plan.m, ld = m + 1, mm = m * m, tid = threadIdx.x;
+  const int ld = m + 1, mm = m * m, tid = threadIdx.x;
   const int q = blockIdx.x, n = lv.n;
   const int i = 2 * q + 1;
   const long o = (long)i << level;
-  double* __restrict__ X = B + plan.X;
+  double* __restrict__ X = B + Xoff;
   double* sFa = sF;
   double* sFb = sFa + m * ld;
   double* sLi = sFb + m * ld;
@@ -529,12 +636,13 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_backsolve(double* __restric
       const int w = tid + u * BCR_THREADS;
       if (w < mm) {
         const int r = w / m, c = w - r * m;
-        sFa[r * ld + c] = v1[u]; sFb[r * ld + c] = v2[u]; sLi[r * ld + c] = v3[u];
+        sFa[r * ld + c] = v1[u]; sFb[r * ld + c] = v2[u]; sLi[c * ld + r] = v3[u];  // (L^-T is stored transposed)
       }
     }
     if (tid < m) { xa[tid] = va; xb[tid] = vb; tt[tid] = vy; }
   }
   __syncthreads();
+  BCR_CUT(1);  // loads
   // t_c = y_c - sum_r Fa[r][c] xa[r] + Fb[r][c] xb[r]: four row groups per column, folded in a fixed order
   const int c = tid & 63, g = tid >> 6;
   if (c < m) {
@@ -555,6 +663,79 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_backsolve(double* __restric
     X[o * m + tid] = x;
     if (tid < 6 * cnt[o]) dc[6L * cam0[o] + tid] = x;
   }
+  BCR_CUT(2);
+  BCR_CUTS_PRINT("k_bcr_backsolve", level, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same back-substitution by ONE WAVE per eliminated block, without LDS and without a barrier (round 3; m <= 36):
+// lane c holds COLUMN c of Fa and Fb (coalesced loads straight into registers) and row c of L^-T (stored transposed for
+// exactly this), all requested in one round; x of the two neighbours and y sit one entry per lane and travel by
+// v_readlane:  t_c = y_c - sum_r Fa[r][c] xa_r - sum_r Fb[r][c] xb_r,   x_c = sum_k L^-T[c][k] t_k  (fixed order).
+// XS: the neighbours' x come from an LDS copy indexed by (level-0 block >> xshift) (the levels that k_bcr_tail folds
+// into its own launch), and x_i goes there as well as to X.
+template <int M, bool XS>
+__device__ __forceinline__ void bcr_backsolve_wave(double* __restrict__ B, const BcrLevel& lv, long Xoff, int level, int q,
+                                                   int lane, const int* __restrict__ cam0, const int* __restrict__ cnt,
+                                                   double* __restrict__ dc, double* xs, int xshift, int done = 0) {
+  constexpr int mm = M * M;
+  const int n = lv.n, i = 2 * q + 1;
+  const long o = (long)i << level, oa = (long)(i - 1) << level, ob = (long)(i + 1 == n ? 0 : i + 1) << level;
+  const int c = lane < M ? lane : 0;
+  double* __restrict__ X = B + Xoff;
+  const double* __restrict__ Fa = B + lv.Fa + (long)q * mm + c;
+  const double* __restrict__ Fb = B + lv.Fb + (long)q * mm + c;
+  const double* __restrict__ Lt = B + lv.LiT + (long)q * mm + c;
+  double fa[M], fb[M], li[M];
+#pragma unroll
+  for (int r = 0; r < M; ++r) { fa[r] = Fa[r * M]; fb[r] = Fb[r * M]; li[r] = Lt[r * M]; }  // li[k] = L^-T[c][k]
+  const double y = B[lv.y + (long)q * M + c];
+  const double xa = XS ? xs[(oa >> xshift) * M + c] : X[oa * M + c];
+  const double xb = XS ? xs[(ob >> xshift) * M + c] : X[ob * M + c];
+  double t0 = y, t1 = 0.0;
+#pragma unroll
+  for (int r = 0; r < M; ++r) {
+    t0 = fma(-fa[r], readlane_f64(xa, r), t0);
+    t1 = fma(-fb[r], readlane_f64(xb, r), t1);
+  }
+  const double t = t0 + t1;
+  double x0 = 0.0, x1 = 0.0;
+#pragma unroll
+  for (int k = 0; k < M; k += 2) {
+    x0 = fma(li[k], readlane_f64(t, k), x0);
+    x1 = fma(li[k + 1], readlane_f64(t, k + 1), x1);
+  }
+  const double x = x0 + x1;
+  if (lane < M && !done) {  // (a launch that follows termination stores nothing)
+    X[o * M + lane] = x;
+    if (XS) xs[(o >> xshift) * M + lane] = x;
+    if (lane < 6 * cnt[o]) dc[6L * cam0[o] + lane] = x;
+  }
+}
+template <bool XS>
+__device__ __forceinline__ bool bcr_backsolve_wave_m(int m, double* __restrict__ B, const BcrLevel& lv, long Xoff, int level,
+                                                     int q, int lane, const int* __restrict__ cam0, const int* __restrict__ cnt,
+                                                     double* __restrict__ dc, double* xs, int xshift, int done = 0) {
+  switch (m) {
+    case 12: bcr_backsolve_wave<12, XS>(B, lv, Xoff, level, q, lane, cam0, cnt, dc, xs, xshift, done); return true;
+    case 18: bcr_backsolve_wave<18, XS>(B, lv, Xoff, level, q, lane, cam0, cnt, dc, xs, xshift, done); return true;
+    case 24: bcr_backsolve_wave<24, XS>(B, lv, Xoff, level, q, lane, cam0, cnt, dc, xs, xshift, done); return true;
+    case 30: bcr_backsolve_wave<30, XS>(B, lv, Xoff, level, q, lane, cam0, cnt, dc, xs, xshift, done); return true;
+    case 36: bcr_backsolve_wave<36, XS>(B, lv, Xoff, level, q, lane, cam0, cnt, dc, xs, xshift, done); return true;
+    default: return false;
+  }
+}
+constexpr int BCR_WAVE_MAX_M = 36;  // block sizes that the wave-per-block back-substitution takes (multiples of 6 from 12)
+__host__ __device__ inline bool bcr_wave_backsolve_ok(int m) { return m >= 12 && m <= BCR_WAVE_MAX_M && m % 6 == 0; }
+
+// four eliminated blocks of a level per workgroup, a wave each
+__global__ __launch_bounds__(BCR_THREADS) void k_bcr_backsolve_w(double* __restrict__ B, BcrLevel lv, int m, long Xoff, int level,
+                                                                 const int* __restrict__ cam0, const int* __restrict__ cnt,
+                                                                 const LmCtrl* ctrl, double* __restrict__ dc) {
+  const int done = ctrl ? ctrl->done : 0;  // requested with the loads, looked at before the stores
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= lv.n_elim) return;
+  (void)bcr_backsolve_wave_m<false>(m, B, lv, Xoff, level, q, threadIdx.x & 63, cam0, cnt, dc, nullptr, 0, done);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -565,12 +746,13 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_backsolve(double* __restric
 //     block (k - 1, k) = -Fa_{e-1} Fb_{e-1}^T,     block (k, k + 1) = -Fa_{e+1} Fb_{e+1}^T   (or E_e where e + 1 does not exist),
 // lays them out as the tall matrix of k_bcr_factor in LDS and factors it: no round trip through memory and one launch
 // per level instead of two.
-__global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_level(double* __restrict__ B, BcrPlan plan, int level, const LmCtrl* ctrl,
+__global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_level(double* __restrict__ B, BcrLevel lv, BcrLevel nx, int m, int level, const LmCtrl* ctrl,
                                                            double* __restrict__ badv) {
-  extern __shared__ double lds[];
+  extern __shared__ __align__(16) double lds[];
+  BCR_CUTS_DECL;
+  BCR_CUT(0);
   const int done = ctrl ? ctrl->done : 0;  // looked at after the first round of loads (see k_bcr_factor)
-  const BcrLevel lv = plan.lv[level], nx = plan.lv[level + 1];
-  const int m = plan.m, ld = m + 1, mm = m * m;
+  const int ld = m + 1, mm = m * m;
   const int tid = threadIdx.x;
   const int k = blockIdx.x, e = 2 * k, n = lv.n;
   const bool elim = (k & 1) != 0;  // eliminated at level l + 1
@@ -632,6 +814,7 @@ __global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_level(double* __restrict
     if (tid < m) { yL[tid] = y1; yR[tid] = y2; }
   }
   __syncthreads();
+  BCR_CUT(1);  // loads
   double* __restrict__ Dn = B + nx.D + (long)k * mm;
   double* __restrict__ En = B + nx.E + (long)k * mm;
   const bool copy_E = qr < 0;                            // n odd, e = n - 1: blocks n - 1 and 0 stay coupled directly
@@ -716,6 +899,7 @@ __global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_level(double* __restrict
     if (elim) T[4 * m * ld + r] = v; else B[nx.r + (long)k * m + r] = v;
   }
   __syncthreads();
+  BCR_CUT(2);  // products
   if (!elim) {
     for (int w = tid; w < mm; w += BCR_THREADS) {  // lower triangle mirrored
       const int r = w / m, c = w - r * m;
@@ -723,9 +907,12 @@ __global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_level(double* __restrict
     }
     return;
   }
-  const bool bad = bcr_factor_T(T, m, ld, tid);
+  const bool bad = bcr_factor_T(T, m, ld, tid, bcr_align16(lds, T + (4 * m + 1) * ld));
+  BCR_CUT(3);  // factor
   bcr_store_factors(B, nx, k >> 1, T, m, ld, tid);
   if (bad && tid == 0) atomic_add_f64(badv, 1.0);
+  BCR_CUT(4);  // stores issued
+  BCR_CUTS_PRINT("k_bcr_level", level, 1);
 }
 
 // The dense tail system out of registers (see bcr_factor_T_regs): lane r of wave 0 holds row r of the lower triangle
@@ -733,7 +920,7 @@ __global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_level(double* __restrict
 // up a COLUMN of L and the backward sweep x = L^-T y runs as ND steps of (one v_readlane, one multiply-add per lane).
 // Returns after a barrier with x in xs[0 .. ND).
 template <int ND>
-__device__ __forceinline__ bool bcr_tail_regs(double* T, int ld, double* xs, int tid) {
+__device__ __forceinline__ bool bcr_tail_regs(double* T, int ld, double* xs, int tid, double* bcast) {
   static_assert(ND + 1 <= 64, "one row per lane");
   bool bad = false;
   if (tid < 64) {
@@ -741,18 +928,9 @@ __device__ __forceinline__ bool bcr_tail_regs(double* T, int ld, double* xs, int
     double row[ND];
 #pragma unroll
     for (int c = 0; c < ND; ++c) row[c] = T[rho * ld + c];
-#pragma unroll
-    for (int j = 0; j < ND; ++j) {
-      double p = readlane_f64(row[j], j);
-      if (!(p > 0.0)) { bad = true; p = 1.0; }
-      double inv = __builtin_amdgcn_rsq(p);
-      inv = inv * fma(-0.5 * p * inv, inv, 1.5);
-      inv = inv * fma(-0.5 * p * inv, inv, 1.5);
-      const double t = row[j] * inv;
-      row[j] = t;
-#pragma unroll
-      for (int c = j + 1; c < ND; ++c) row[c] = fma(-t, readlane_f64(t, c), row[c]);
-    }
+    double tp = 0.0;
+    double2 bc[ND / 2];
+    bcr_reg_steps<ND>(row, bc, tp, bad, bcast, lane);
     // rows back to LDS (ld is odd: conflict-free), then lane j takes column j of L and y_j
     if (lane <= ND) {
 #pragma unroll
@@ -784,18 +962,48 @@ __device__ __forceinline__ bool bcr_tail_regs(double* T, int ld, double* xs, int
 // couplings of blocks 0 and 1 land on the same block), factored by the block Cholesky loop of k_bcr_factor (the
 // right-hand-side row comes out as y = L^-1 r), then solved backwards column block by column block
 // (x_j = L_jj^-T y_j;  y_rho -= L[j][rho] x_j for the rows above).  Writes x of the tail blocks to X and to dc.
-__global__ __launch_bounds__(BCR_THREADS) void k_bcr_tail(double* __restrict__ B, BcrPlan plan, const int* __restrict__ cam0,
+__global__ __launch_bounds__(BCR_THREADS) void k_bcr_tail(double* __restrict__ B, BcrLevel lv, int m, long Xoff, int level, const int* __restrict__ cam0,
                                                           const int* __restrict__ cnt, const LmCtrl* ctrl,
-                                                          double* __restrict__ dc, double* __restrict__ badv) {
-  extern __shared__ double lds[];
-  if (ctrl && ctrl->done) return;
-  const int level = plan.n_levels;
-  const BcrLevel lv = plan.lv[level];
-  const int m = plan.m, mm = m * m, n = lv.n, Nd = n * m, ld = Nd + 1, nb = Nd / 6, R = Nd + 1;
+                                                          double* __restrict__ dc, double* __restrict__ badv, BcrTop top) {
+  extern __shared__ __align__(16) double lds[];
+  BCR_CUTS_DECL;
+  BCR_CUT(0);
+  const int done = ctrl ? ctrl->done : 0;  // looked at after the round of loads (see k_bcr_factor)
+  const int mm = m * m, n = lv.n, Nd = n * m, ld = Nd + 1, nb = Nd / 6, R = Nd + 1;
   const int tid = threadIdx.x;
   double* T = lds;                      // [R][ld]
   double* sLi = T + (long)R * ld;       // [nb][36] inverses of the diagonal blocks of L
   double* xs = sLi + nb * 36;           // [Nd]
+  const bool two_in_regs = n == 2 && (Nd == 48 || Nd == 60);  // the usual tail: two blocks, solved out of registers
+  if (two_in_regs) {
+    // [D_0 . ; E_0^T + E_1  D_1 | r]: every entry of the lower triangle has one writer, everything is requested in ONE
+    // round of loads, and nothing is cleared (bcr_tail_regs never lets an entry above the diagonal reach a result)
+    double d0[BCR_EPT], d1[BCR_EPT], e0[BCR_EPT], e1[BCR_EPT];
+#pragma unroll
+    for (int u = 0; u < BCR_EPT; ++u) {
+      const int w = tid + u * BCR_THREADS;
+      d0[u] = d1[u] = e0[u] = e1[u] = 0.0;
+      if (w < mm) {
+        const int r = w / m, c = w - r * m;
+        d0[u] = B[lv.D + w]; d1[u] = B[lv.D + mm + w];
+        e0[u] = B[lv.E + c * m + r];  // E_0^T: block (1, 0)
+        e1[u] = B[lv.E + mm + w];     // E_1 = block (1, 0) as it is (the loop closure)
+      }
+    }
+    const double rv = tid < Nd ? B[lv.r + tid] : 0.0;
+    if (done) return;
+#pragma unroll
+    for (int u = 0; u < BCR_EPT; ++u) {
+      const int w = tid + u * BCR_THREADS;
+      if (w < mm) {
+        const int r = w / m, c = w - r * m;
+        if (c <= r) { T[r * ld + c] = d0[u]; T[(m + r) * ld + m + c] = d1[u]; }
+        T[(m + r) * ld + c] = e0[u] + e1[u];
+      }
+    }
+    if (tid < Nd) T[Nd * ld + tid] = rv;
+  } else {
+  if (done) return;
   for (int e = tid; e < R * ld; e += BCR_THREADS) T[e] = 0.0;
   __syncthreads();
   // D, E, r of the level: eight loads in flight per thread and round (a plain strided loop would wait for every
@@ -850,13 +1058,15 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_tail(double* __restrict__ B
       if (w < mm) { const int r = w / m, c = w - r * m; T[((n - 1) * m + r) * ld + c] += vl[u]; }
     }
   }
+  }
   __syncthreads();
+  BCR_CUT(1);  // assembly in LDS
   bool bad = false;
   bool in_regs = true;
   switch (Nd) {  // a row of the dense system per lane of ONE wave (Nd + 1 <= 64 rows): bcr_tail_regs
-    case 48: bad = bcr_tail_regs<48>(T, ld, xs, tid); break;
-    case 54: bad = bcr_tail_regs<54>(T, ld, xs, tid); break;
-    case 60: bad = bcr_tail_regs<60>(T, ld, xs, tid); break;
+    case 48: bad = bcr_tail_regs<48>(T, ld, xs, tid, bcr_align16(lds, xs + Nd)); break;
+    case 54: bad = bcr_tail_regs<54>(T, ld, xs, tid, bcr_align16(lds, xs + Nd)); break;
+    case 60: bad = bcr_tail_regs<60>(T, ld, xs, tid, bcr_align16(lds, xs + Nd)); break;
     default: in_regs = false; break;
   }
   if (!in_regs) {
@@ -912,12 +1122,22 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_tail(double* __restrict__ B
       __syncthreads();
     }
   }
-  double* __restrict__ X = B + plan.X;
+  BCR_CUT(2);  // factor + sweep
+  double* __restrict__ X = B + Xoff;
+  double* xtop = bcr_align16(lds, xs + Nd) + BCR_BCAST;  // [top.nx][m]: x of the blocks of the folded levels
   for (int e = tid; e < Nd; e += BCR_THREADS) {
     const int i = e / m, c = e - i * m;
     const long o = (long)i << level;
     X[o * m + c] = xs[e];
+    if (top.n > 0) xtop[(o >> top.xshift) * m + c] = xs[e];
     if (c < 6 * cnt[o]) dc[6L * cam0[o] + c] = xs[e];
   }
   if (bad && tid == 0) atomic_add_f64(badv, 1.0);
+  for (int t = 0; t < top.n; ++t) {  // the top back-substitution levels, highest first: a wave per eliminated block
+    __syncthreads();                  // x of the level above is in xtop
+    for (int q = tid >> 6; q < top.lv[t].n_elim; q += BCR_THREADS / 64)
+      (void)bcr_backsolve_wave_m<true>(m, B, top.lv[t], Xoff, top.level[t], q, tid & 63, cam0, cnt, dc, xtop, top.xshift);
+  }
+  BCR_CUT(3);
+  BCR_CUTS_PRINT("k_bcr_tail", level, 0);
 }

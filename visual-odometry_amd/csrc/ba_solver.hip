@@ -157,6 +157,7 @@ struct ba_handle {
   // block cyclic reduction of a trajectory's reduced system (ba_bcr.h)
   bool bcr_solve = false;
   BcrPlan bcr_plan{};
+  BcrTop bcr_top{};          // the back-substitution levels that k_bcr_tail runs itself
   double* bcr_B = nullptr;
   size_t bcr_zero = 0;  // doubles of the level-0 arrays (cleared once, in ba_set_problem)
   bool bcr_direct = false;  // k_gather_S_wave writes the level-0 arrays itself (no k_bcr_assemble launch in solver mode)
@@ -583,23 +584,31 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
     if (!bcr_direct)
       launch_timed(h, KT_PCG, k_bcr_assemble, grid_for((long)d.nu * 36 + 6L * d.Cf + h->bcr_npad), 256, d, B, pl.m, h->bcr_dst,
                    h->bcr_dst2, h->bcr_kind, h->bcr_rdst, h->bcr_pad, h->bcr_npad, lam, o.min_diag, mode);
+    const int m = pl.m;
     if (h->bcr_fused && pl.n_levels > 0) {
       // factor of level 0; then one launch per level: the update of level l with the factor of level l + 1; the last
       // update leaves the tail system
-      launch_timed_lds(h, KT_PCG, k_bcr_factor, pl.lv[0].n_elim, BCR_THREADS, h->bcr_lds_factor, B, pl, 0, ctrl, d.scal + SC_BADV);
+      launch_timed_lds(h, KT_PCG, k_bcr_factor, pl.lv[0].n_elim, BCR_THREADS, h->bcr_lds_factor, B, pl.lv[0], m, ctrl, d.scal + SC_BADV);
       for (int l = 0; l + 1 < pl.n_levels; ++l)
-        launch_timed_lds(h, KT_PCG, k_bcr_level, pl.lv[l + 1].n, BCR_THREADS, h->bcr_lds_level, B, pl, l, ctrl, d.scal + SC_BADV);
-      launch_timed_lds(h, KT_PCG, k_bcr_update, pl.lv[pl.n_levels].n, BCR_THREADS, h->bcr_lds_update, B, pl, pl.n_levels - 1, ctrl);
+        launch_timed_lds(h, KT_PCG, k_bcr_level, pl.lv[l + 1].n, BCR_THREADS, h->bcr_lds_level, B, pl.lv[l], pl.lv[l + 1], m, l, ctrl,
+                         d.scal + SC_BADV);
+      launch_timed_lds(h, KT_PCG, k_bcr_update, pl.lv[pl.n_levels].n, BCR_THREADS, h->bcr_lds_update, B, pl.lv[pl.n_levels - 1],
+                       pl.lv[pl.n_levels], m, ctrl);
     } else {
       for (int l = 0; l < pl.n_levels; ++l) {
-        launch_timed_lds(h, KT_PCG, k_bcr_factor, pl.lv[l].n_elim, BCR_THREADS, h->bcr_lds_factor, B, pl, l, ctrl, d.scal + SC_BADV);
-        launch_timed_lds(h, KT_PCG, k_bcr_update, pl.lv[l + 1].n, BCR_THREADS, h->bcr_lds_update, B, pl, l, ctrl);
+        launch_timed_lds(h, KT_PCG, k_bcr_factor, pl.lv[l].n_elim, BCR_THREADS, h->bcr_lds_factor, B, pl.lv[l], m, ctrl, d.scal + SC_BADV);
+        launch_timed_lds(h, KT_PCG, k_bcr_update, pl.lv[l + 1].n, BCR_THREADS, h->bcr_lds_update, B, pl.lv[l], pl.lv[l + 1], m, ctrl);
       }
     }
-    launch_timed_lds(h, KT_PCG, k_bcr_tail, 1, BCR_THREADS, h->bcr_lds_tail, B, pl, h->bcr_cam0, h->bcr_cnt, ctrl, d.dc,
-                     d.scal + SC_BADV);
-    for (int l = pl.n_levels - 1; l >= 0; --l)
-      launch_timed(h, KT_PCG, k_bcr_backsolve, pl.lv[l].n_elim, BCR_THREADS, B, pl, l, h->bcr_cam0, h->bcr_cnt, ctrl, d.dc);
+    launch_timed_lds(h, KT_PCG, k_bcr_tail, 1, BCR_THREADS, h->bcr_lds_tail, B, pl.lv[pl.n_levels], m, pl.X, pl.n_levels, h->bcr_cam0,
+                     h->bcr_cnt, ctrl, d.dc, d.scal + SC_BADV, h->bcr_top);
+    for (int l = pl.n_levels - 1 - h->bcr_top.n; l >= 0; --l) {
+      if (bcr_wave_backsolve_ok(m))
+        launch_timed(h, KT_PCG, k_bcr_backsolve_w, grid_for(pl.lv[l].n_elim, 4), BCR_THREADS, B, pl.lv[l], m, pl.X, l, h->bcr_cam0,
+                     h->bcr_cnt, ctrl, d.dc);
+      else
+        launch_timed(h, KT_PCG, k_bcr_backsolve, pl.lv[l].n_elim, BCR_THREADS, B, pl.lv[l], m, pl.X, l, h->bcr_cam0, h->bcr_cnt, ctrl, d.dc);
+    }
     *pcg_iters = -1;
     return BA_OK;
   }
@@ -1926,17 +1935,28 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
           h->bcr_npad = (int)h->h_bpad.size();
           h->bcr_plan = pl;
           h->bcr_solve = true;
-          h->bcr_lds_factor = (size_t)(4 * m + 1) * (m + 1) * sizeof(double);
+          h->bcr_lds_factor = ((size_t)(4 * m + 1) * (m + 1) + BCR_BCAST) * sizeof(double);
           h->bcr_lds_update = ((size_t)4 * m * (m + 1) + 2 * m) * sizeof(double);
           HIP_TRY(h, hipFuncSetAttribute((const void*)k_bcr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bcr_lds_factor));
           HIP_TRY(h, hipFuncSetAttribute((const void*)k_bcr_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bcr_lds_update));
-          h->bcr_lds_level = ((size_t)(4 * m + 4 * m + 1) * (m + 1) + 2 * m) * sizeof(double);
+          h->bcr_lds_level = ((size_t)(4 * m + 4 * m + 1) * (m + 1) + 2 * m + BCR_BCAST) * sizeof(double);
           h->bcr_fused = env_int("BA_BCR_FUSED", 1) != 0 && h->bcr_lds_level <= 160 * 1024;
           if (h->bcr_fused)
             HIP_TRY(h, hipFuncSetAttribute((const void*)k_bcr_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bcr_lds_level));
           {
+            // the top back-substitution levels go into the tail's launch while they have at most 8 blocks each
+            BcrTop top{};
+            if (bcr_wave_backsolve_ok(m) && env_int("BA_BCR_TOP", 1) != 0)
+              for (int l = pl.n_levels - 1; l >= 0 && top.n < BCR_TOP_MAX && pl.lv[l].n_elim <= 8 && pl.lv[l].n <= 32; --l) {
+                top.level[top.n] = l;
+                top.lv[top.n] = pl.lv[l];
+                top.xshift = l;
+                top.nx = pl.lv[l].n;
+                ++top.n;
+              }
+            h->bcr_top = top;
             const size_t nd = (size_t)pl.lv[pl.n_levels].n * m;
-            h->bcr_lds_tail = ((nd + 1) * (nd + 1) + (nd / 6) * 36 + nd) * sizeof(double);
+            h->bcr_lds_tail = ((nd + 1) * (nd + 1) + (nd / 6) * 36 + nd + BCR_BCAST + 2 + (size_t)top.nx * m) * sizeof(double);
             HIP_TRY(h, hipFuncSetAttribute((const void*)k_bcr_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bcr_lds_tail));
           }
           h->banded_solve = false; h->bseg_P = 0; h->dense_solve = false; h->small_solve = false;
