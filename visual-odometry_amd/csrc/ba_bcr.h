@@ -252,7 +252,7 @@ __device__ __forceinline__ void bcr_reg_steps(double (&row)[M], double2 (&bc)[M 
 }
 
 template <int M>
-__device__ __forceinline__ bool bcr_factor_T_regs(double* T, int ld, int tid, double* bcast) {
+__device__ __forceinline__ bool bcr_factor_T_regs(double* T, int ld, int tid, double* bcast, const double* sub) {
   static_assert(M % 2 == 0, "the broadcast reads take the columns two at a time");
   constexpr int EXTRA = 3 * M + 1, EPW = (EXTRA + 3) / 4;  // rows below D, and their share per wave
   static_assert(M + EPW <= 64, "a wave holds the rows of D and its share of the rows below in its 64 lanes");
@@ -263,6 +263,10 @@ __device__ __forceinline__ bool bcr_factor_T_regs(double* T, int ld, int tid, do
   double row[M];
 #pragma unroll
   for (int c = 0; c < M; ++c) row[c] = T[rho * ld + c];
+  if (sub != nullptr && lane < M) {  // a part of D that another wave left beside T (k_bcr_level, m = 24)
+#pragma unroll
+    for (int c = 0; c < M; ++c) row[c] -= sub[rho * ld + c];
+  }
   bool bad = false;
   double tp = 0.0;
   double2 bc[M / 2];
@@ -277,13 +281,13 @@ __device__ __forceinline__ bool bcr_factor_T_regs(double* T, int ld, int tid, do
 
 // The block Cholesky of the tall matrix T = [D ; Ea ; Eb^T ; I ; r^T] ((4 m + 1) x m in LDS, row stride ld): see
 // k_bcr_factor.  Called by every thread of the workgroup after a barrier that made T visible; returns with a barrier.
-__device__ __forceinline__ bool bcr_factor_T(double* T, int m, int ld, int tid, double* bcast) {
+__device__ __forceinline__ bool bcr_factor_T(double* T, int m, int ld, int tid, double* bcast, const double* sub = nullptr) {
   switch (m) {  // (the rows below D come back in T; the rows of D themselves are not needed afterwards)
-    case 12: return bcr_factor_T_regs<12>(T, ld, tid, bcast);
-    case 18: return bcr_factor_T_regs<18>(T, ld, tid, bcast);
-    case 24: return bcr_factor_T_regs<24>(T, ld, tid, bcast);
-    case 30: return bcr_factor_T_regs<30>(T, ld, tid, bcast);
-    case 36: return bcr_factor_T_regs<36>(T, ld, tid, bcast);
+    case 12: return bcr_factor_T_regs<12>(T, ld, tid, bcast, sub);
+    case 18: return bcr_factor_T_regs<18>(T, ld, tid, bcast, sub);
+    case 24: return bcr_factor_T_regs<24>(T, ld, tid, bcast, sub);
+    case 30: return bcr_factor_T_regs<30>(T, ld, tid, bcast, sub);
+    case 36: return bcr_factor_T_regs<36>(T, ld, tid, bcast, sub);
     default: break;
   }
   const int nb = m / 6, R = 4 * m + 1;
@@ -460,6 +464,32 @@ constexpr int BCR_FPW2 = (2 * BCR_MT * BCR_MT + 3) / 4;             // tiles of 
 constexpr int BCR_ROUNDS1 = (2 * BCR_LPW + BCR_FPW1 + BCR_CHAINS - 1) / BCR_CHAINS;
 constexpr int BCR_ROUNDS2 = (2 * BCR_LPW + BCR_FPW2 + BCR_CHAINS - 1) / BCR_CHAINS;
 static_assert(BCR_THREADS == 256, "the tile schedule below assumes four waves");
+
+// ------------------------------------------------------------------------------------------------
+// m = 24 (tracks of five: four cameras per super-block): a whole 24 x 24 product C += X Y^T by ONE wave on the vector
+// unit, a 3 x 3 tile of C per lane (lane = 8 ti + tj: rows 3 ti .. 3 ti + 2 of X against rows 3 tj .. of Y), two k at a
+// time: six 16-byte LDS reads feed 18 multiply-adds, eight distinct rows per read instruction (stride 75 doubles: no
+// bank conflict; the lanes of a row get a broadcast).  The fp64 matrix instruction needs 16-wide tiles: 24 = 16 + 8
+// wastes 44 % of its work, and it issues once per ~140 cycles on this part: the four products of a level took 3.4 us on
+// it (wall_clock64), with one wave per product here they take under 1 us.
+__device__ __forceinline__ void bcr_gemm24_xyt(const double* X, const double* Y, int lane, double (&acc)[9]) {
+  constexpr int M = 24, LD = M + 1;
+  const double* xr = X + 3 * (lane >> 3) * LD;
+  const double* yr = Y + 3 * (lane & 7) * LD;
+#pragma unroll
+  for (int k = 0; k < M; k += 2) {
+    double xa[3][2], yb[3][2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      xa[a][0] = xr[a * LD + k]; xa[a][1] = xr[a * LD + k + 1];
+      yb[a][0] = yr[a * LD + k]; yb[a][1] = yr[a * LD + k + 1];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) acc[3 * a + b] = fma(xa[a][1], yb[b][1], fma(xa[a][0], yb[b][0], acc[3 * a + b]));
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // k_bcr_update: one workgroup per even block e of level l = block e / 2 of level l + 1 (formulas in the header).
@@ -771,6 +801,9 @@ __global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_level(double* __restrict
   const int lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int MT = (m + 15) >> 4, nlow = MT * (MT + 1) / 2, nfull = MT * MT;
   double de[BCR_LPW][4], re = 0.0;
+  const bool m24 = m == 24;  // products on the vector unit, a wave per product (bcr_gemm24_xyt)
+  double de9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double* P2s = bcr_align16(lds, T + (4 * m + 1) * ld) + BCR_BCAST;  // [m][ld] (m = 24 only)
   const int rrow = tid - 3 * 64;  // r' is formed by the last wave, which gets the fewest tiles: row rrow by lane rrow
   {
     double v1[BCR_EPT], v2[BCR_EPT], v3[BCR_EPT], v4[BCR_EPT];
@@ -791,15 +824,24 @@ __global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_level(double* __restrict
     if (rrow >= 0 && rrow < m) re = B[lv.r + (long)e * m + rrow];
     // the entries of D_e that this thread's tiles update: in flight with the factor blocks, not a second round trip
     // after the products
+    if (m24) {  // the 3 x 3 tile of D_e that lane (ti, tj) of wave 0 updates (bcr_gemm24_xyt's layout)
+      if (wv == 0) {
 #pragma unroll
-    for (int p = 0; p < BCR_LPW; ++p) {
-      int ti, tj;
-      bcr_lower_tile(wv + 4 * p, ti, tj);
-      const int c = 16 * tj + l15;
+        for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int r = 16 * ti + l4 + 4 * q;
-        de[p][q] = (wv + 4 * p < nlow && r < m && c < m) ? De[r * m + c] : 0.0;
+          for (int b2 = 0; b2 < 3; ++b2) de9[3 * a + b2] = De[(3 * (lane >> 3) + a) * 24 + 3 * (lane & 7) + b2];
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < BCR_LPW; ++p) {
+        int ti, tj;
+        bcr_lower_tile(wv + 4 * p, ti, tj);
+        const int c = 16 * tj + l15;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 16 * ti + l4 + 4 * q;
+          de[p][q] = (wv + 4 * p < nlow && r < m && c < m) ? De[r * m + c] : 0.0;
+        }
       }
     }
     if (done) return;
@@ -821,6 +863,43 @@ __global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_level(double* __restrict
   const bool need_E = !elim && k == nx.n - 1;             // an even block's E' is only read where it is the last block of an
                                                          // odd count (its right neighbour is block 0: the coupling is copied)
   {
+    if (m24) {
+      // wave 0: D' = D_e - FbL FbL^T - FaR FaR^T;  wave 1: Ea' = -FaL FbL^T (elim) or E' = -FaR FbR^T (need_E);
+      // wave 2: Eb'^T = -FbR FaR^T (elim);  wave 3: r' below.  A block without a neighbour has zeros in its place.
+      const int r0 = 3 * (lane >> 3), c0 = 3 * (lane & 7);
+      double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      if (wv == 0) {  // (the second product of D' is wave 3's: added in after the barrier below)
+        bcr_gemm24_xyt(FbL, FbL, lane, acc);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b2 = 0; b2 < 3; ++b2) T[(r0 + a) * ld + c0 + b2] = de9[3 * a + b2] - acc[3 * a + b2];
+      } else if (wv == 3) {  // FaR FaR^T, left beside T: whoever reads D' after the barrier subtracts it
+        bcr_gemm24_xyt(FaR, FaR, lane, acc);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b2 = 0; b2 < 3; ++b2) P2s[(r0 + a) * ld + c0 + b2] = acc[3 * a + b2];
+      } else if (wv == 1 && elim) {
+        bcr_gemm24_xyt(FaL, FbL, lane, acc);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b2 = 0; b2 < 3; ++b2) T[(m + r0 + a) * ld + c0 + b2] = -acc[3 * a + b2];
+      } else if (wv == 1 && need_E && !copy_E) {
+        bcr_gemm24_xyt(FaR, FbR, lane, acc);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b2 = 0; b2 < 3; ++b2) En[(r0 + a) * m + c0 + b2] = -acc[3 * a + b2];
+      } else if (wv == 2 && elim && !copy_E) {
+        bcr_gemm24_xyt(FbR, FaR, lane, acc);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b2 = 0; b2 < 3; ++b2) T[(2 * m + r0 + a) * ld + c0 + b2] = -acc[3 * a + b2];
+      }
+    } else {
     // the jobs of this wave, in order: the two products of each of its lower tiles of D' = D_e - FbL FbL^T - FaR FaR^T
     // (tiles wv, wv + 4, ...), then, continuing the round robin over the waves, its tiles of
     //   elim:    Ea' = block (k - 1, k) = -FaL FbL^T  (tag 2)  and  Eb'^T = (block (k, k + 1))^T = -FbR FaR^T  (tag 3;
@@ -878,6 +957,7 @@ __global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_level(double* __restrict
         }
       }
     }
+    }
     if (elim) {
       for (int w = tid; w < mm; w += BCR_THREADS) {
         const int r = w / m, c = w - r * m;
@@ -903,11 +983,12 @@ __global__ __launch_bounds__(BCR_THREADS, 2) void k_bcr_level(double* __restrict
   if (!elim) {
     for (int w = tid; w < mm; w += BCR_THREADS) {  // lower triangle mirrored
       const int r = w / m, c = w - r * m;
-      Dn[w] = c <= r ? T[r * ld + c] : T[c * ld + r];
+      const int at = c <= r ? r * ld + c : c * ld + r;
+      Dn[w] = m24 ? T[at] - P2s[at] : T[at];
     }
     return;
   }
-  const bool bad = bcr_factor_T(T, m, ld, tid, bcr_align16(lds, T + (4 * m + 1) * ld));
+  const bool bad = bcr_factor_T(T, m, ld, tid, bcr_align16(lds, T + (4 * m + 1) * ld), m24 ? P2s : nullptr);
   BCR_CUT(3);  // factor
   bcr_store_factors(B, nx, k >> 1, T, m, ld, tid);
   if (bad && tid == 0) atomic_add_f64(badv, 1.0);

@@ -1939,7 +1939,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
           h->bcr_lds_update = ((size_t)4 * m * (m + 1) + 2 * m) * sizeof(double);
           HIP_TRY(h, hipFuncSetAttribute((const void*)k_bcr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bcr_lds_factor));
           HIP_TRY(h, hipFuncSetAttribute((const void*)k_bcr_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bcr_lds_update));
-          h->bcr_lds_level = ((size_t)(4 * m + 4 * m + 1) * (m + 1) + 2 * m + BCR_BCAST) * sizeof(double);
+          h->bcr_lds_level = ((size_t)(4 * m + 4 * m + 1) * (m + 1) + 2 * m + BCR_BCAST + (size_t)m * (m + 1)) * sizeof(double);
           h->bcr_fused = env_int("BA_BCR_FUSED", 1) != 0 && h->bcr_lds_level <= 160 * 1024;
           if (h->bcr_fused)
             HIP_TRY(h, hipFuncSetAttribute((const void*)k_bcr_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bcr_lds_level));
