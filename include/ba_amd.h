@@ -310,6 +310,13 @@ int ba_comm_init(ba_handle* h, int32_t rank, int32_t world, const char* id128);
  * for a handle without one.  No reference counterpart; bench.py's `n_gpus` is this figure. */
 int ba_comm_info(const ba_handle* h, int32_t* rank, int32_t* world);
 
+/* Digests of the index tables that the last ba_set_problem built and uploaded (the internal observation order, the block
+ * pattern of S, the chunk / group / write-out / gather tables of the kernels), one 64-bit value per table in upload order;
+ * recorded only when the environment holds BA_TABLE_DIGEST=1 (else *count = 0).  `out` receives min(cap, *count) values.
+ * No reference counterpart (the reference has no tables: its pattern is the jac_sparsity mask of
+ * bundle_adjustment.py:90-154); tests use it to assert that a faster set-up builds the same tables bit for bit. */
+int ba_debug_table_digests(const ba_handle* h, uint64_t* out, int32_t cap, int32_t* count);
+
 /* Which solver ba_set_problem chose for the reduced camera system: 0 multi-kernel PCG, 1 one-workgroup PCG,
  * 2 whole-GPU dense Cholesky, 3 banded + arrow Cholesky, 4 dense Cholesky per connected component (batched
  * windows), 5 block cyclic reduction.  No reference counterpart. */

@@ -1,0 +1,66 @@
+"""ba_set_problem's index tables (the internal observation order, the block pattern of S, the chunk / group / write-out /
+gather tables) are built on host threads since round 3.  tests/golden/table_digests.json holds a digest of every table
+as round 2's single-threaded set-up built it (tools/table_digests.py, commit 9e72c13): the threaded set-up must give the
+same bits for every scene there, whatever the number of threads.  No reference counterpart (the reference's only
+set-up is the jac_sparsity mask, bundle_adjustment.py:90-154)."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def recorded():
+    with open(os.path.join(ROOT, "tests", "golden", "table_digests.json")) as fh:
+        return json.load(fh)
+
+
+@pytest.fixture(scope="module")
+def cases():
+    import table_digests
+    return table_digests.cases(full=False)
+
+
+@pytest.mark.parametrize("threads", [None, 1, 3, 16])
+def test_tables_are_bit_identical_to_the_single_threaded_setup(recorded, cases, threads, monkeypatch):
+    import table_digests
+    monkeypatch.setenv("BA_TABLE_DIGEST", "1")
+    if threads is None:
+        monkeypatch.delenv("BA_HOST_THREADS", raising=False)
+    else:
+        monkeypatch.setenv("BA_HOST_THREADS", str(threads))
+    for name, case in cases.items():
+        got, solver = table_digests.digests(case)
+        assert solver == recorded[name]["solver"], name
+        assert [f"{v:016x}" for v in got] == recorded[name]["digests"], (name, threads)
+
+
+def test_tables_of_config4_and_the_setup_time(recorded):
+    """BASELINE configs[3] (10 M observations): the same tables as round 2's, and the set-up inside VERDICT r2's bound
+    (150 ms; it was 650 ms) with some slack for a busy host."""
+    import scenes
+    from src import _native
+    sc = scenes.ring_scene(10000, 2000000, 5)
+    os.environ["BA_TABLE_DIGEST"] = "1"
+    try:
+        with _native.Solver() as s:
+            s.set_problem(10000, 2000000, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+            got = s.table_digests()
+    finally:
+        del os.environ["BA_TABLE_DIGEST"]
+    assert [f"{v:016x}" for v in got] == recorded["ring_10000x2000000"]["digests"]
+    import time
+    best = 1e9
+    with _native.Solver() as s:
+        for _ in range(3):
+            t0 = time.perf_counter()
+            s.set_problem(10000, 2000000, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+            best = min(best, 1e3 * (time.perf_counter() - t0))
+    print(f"config 4: ba_set_problem returns after {best:.1f} ms (validation included)")
+    assert best < 250.0

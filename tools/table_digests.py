@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Digests of the tables ba_set_problem builds (ba_debug_table_digests) for a fixed list of scenes.
+
+    BA_TABLE_DIGEST=1 python tools/table_digests.py [--full] > tests/golden/table_digests.json
+
+The committed file was written by the single-threaded set-up of round 2 (commit 9e72c13); tests/test_gpu_setup.py asserts
+that today's set-up reproduces every value, whatever BA_HOST_THREADS says."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "visual-odometry_amd"))
+import numpy as np  # noqa: E402
+import scenes  # noqa: E402
+from src import _native  # noqa: E402
+
+
+def cases(full: bool):
+    """name -> (C, L, obs_cam, obs_pt, obs_uv, intr, fixed, options)"""
+    out = {}
+
+    def ring(name, C, L, d, **kw):
+        sc = scenes.ring_scene(C, L, d, **kw)
+        out[name] = (C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"], None, {})
+
+    ring("ring_50x2000", 50, 2000, 10)
+    ring("ring_50x20000", 50, 20000, 10)
+    ring("ring_1000x200000", 1000, 200000, 5)
+    ring("ring_120x6000", 120, 6000, 5)
+    ring("random_40x4000", 40, 4000, 6, visibility="random")
+    ring("random_300x30000", 300, 30000, 4, visibility="random")
+    if full:
+        ring("ring_10000x2000000", 10000, 2000000, 5)
+    # shuffled observation order, two fixed cameras, landmarks nobody sees
+    sc = scenes.ring_scene(60, 6000, 7, seed=3)
+    rng = np.random.default_rng(11)
+    keep = rng.permutation(len(sc["obs_cam"]))
+    keep = keep[sc["obs_pt"][keep] % 17 != 5]
+    fixed = np.zeros(60, dtype=np.uint8)
+    fixed[[0, 31]] = 1
+    out["shuffled_60x6000_two_fixed"] = (60, 6000, sc["obs_cam"][keep], sc["obs_pt"][keep], sc["obs_uv"][keep], sc["intr"],
+                                         fixed, {})
+    # 64 windows of config 5 as ONE problem with 64 components (what ba_solve_batched hands to ba_set_problem)
+    cams, pts, uvs, fx = [], [], [], []
+    for b in range(64):
+        w = scenes.local_window_scene(b, K=10, L=100)
+        cams.append(w["obs_cam"] + 10 * b); pts.append(w["obs_pt"] + 100 * b); uvs.append(w["obs_uv"])
+        f = np.zeros(10, dtype=np.uint8); f[0] = 1; fx.append(f)
+    out["windows_64x10x100"] = (640, 6400, np.concatenate(cams).astype(np.int32), np.concatenate(pts).astype(np.int32),
+                                np.vstack(uvs), w["intr"], np.concatenate(fx), {})
+    # a long open trajectory for the banded solver, and the cyclic reduction's equal-split layout
+    ring("ring_998x99800", 998, 99800, 5)
+    return out
+
+
+def digests(case, **env):
+    C, L, oc, op, uv, intr, fixed, opts = case
+    with _native.Solver(**opts) as s:
+        s.set_problem(C, L, oc, op, uv, intr, fixed=fixed)
+        return s.table_digests(), s.reduced_solver()
+
+
+if __name__ == "__main__":
+    assert os.environ.get("BA_TABLE_DIGEST") == "1", "run with BA_TABLE_DIGEST=1"
+    res = {}
+    for name, case in cases("--full" in sys.argv).items():
+        d, solver = digests(case)
+        res[name] = {"solver": solver, "digests": [f"{v:016x}" for v in d]}
+        print(name, solver, len(d), file=sys.stderr)
+    json.dump(res, sys.stdout, indent=1)

@@ -9,6 +9,7 @@
 #include "ba_prior.h"
 #include "ba_coarse.h"
 #include "ba_components.h"
+#include "host_parallel.h"
 
 #include <algorithm>
 #include <chrono>
@@ -18,7 +19,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <memory>
 #include <string>
+#include <thread>
 #include <limits>
 #include <mutex>
 #include <vector>
@@ -104,6 +107,8 @@ double* static_scratch_ptr[ST_MAX_DEVICES] = {};  // per device: the address of 
 std::mutex static_scratch_mutex;                  // calls that overlap on one GPU would race on its array: serialised
 }  // namespace
 
+struct PendingDev { void** out; const void* src; size_t bytes; };  // a queued device array (queue_alloc / queue_upload)
+
 struct ba_handle {
   ba_options opt;
   std::string err;
@@ -111,6 +116,9 @@ struct ba_handle {
   hipStream_t stream = nullptr;
   bool has_problem = false, has_guess = false, has_estimate = false;
   double setup_ms = 0.0;
+  bool digest_on = false;               // BA_TABLE_DIGEST=1: dev_upload records a digest of every table it uploads
+  std::vector<uint64_t> table_digests;  // in upload order (ba_debug_table_digests)
+  std::vector<PendingDev> pending;        // queue_alloc / queue_upload requests until dev_commit
 
   // host copies of the structure
   int C = 0, Cf = 0, L = 0, L_obs = 0, n = 0;
@@ -338,13 +346,88 @@ int dev_alloc(ba_handle* h, T** out, size_t count) {
   return BA_OK;
 }
 
+// 64-bit digest of a table's bytes (length included): what ba_debug_table_digests reports
+uint64_t digest_bytes(const void* ptr, size_t bytes) {
+  const unsigned char* b = static_cast<const unsigned char*>(ptr);
+  uint64_t x = 0x9E3779B97F4A7C15ull ^ (uint64_t)bytes;
+  size_t i = 0;
+  for (; i + 8 <= bytes; i += 8) {
+    uint64_t w;
+    std::memcpy(&w, b + i, 8);
+    x = (x ^ w) * 0x100000001B3ull;
+    x ^= x >> 29;
+  }
+  for (; i < bytes; ++i) x = (x ^ b[i]) * 0x100000001B3ull;
+  return x;
+}
+
 template <class T>
 int dev_upload(ba_handle* h, const T** out, const std::vector<T>& v) {
+  if (h->digest_on) h->table_digests.push_back(digest_bytes(v.data(), v.size() * sizeof(T)));
   T* p = nullptr;
   int rc = dev_alloc(h, &p, v.size());
   if (rc) return rc;
   if (!v.empty()) HIP_TRY(h, hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   *out = p;
+  return BA_OK;
+}
+
+// ba_set_problem's tables and state arrays: queued, then ONE device allocation for all of them (dev_commit) instead of
+// a hipMalloc and a blocking copy per table (about ninety of each: 2.3 ms of a 12 ms set-up at BASELINE configs[1]).
+// The small tables travel in one staging copy, the large ones one copy each, straight from their vectors, which must
+// stay alive until dev_commit.
+template <class T>
+void queue_alloc(ba_handle* h, T** out, size_t count) {
+  h->pending.push_back(PendingDev{reinterpret_cast<void**>(out), nullptr, std::max<size_t>(count, 1) * sizeof(T)});
+}
+template <class T, class A>
+void queue_upload(ba_handle* h, const T** out, const std::vector<T, A>& v) {
+  if (h->digest_on) h->table_digests.push_back(digest_bytes(v.data(), v.size() * sizeof(T)));
+  h->pending.push_back(PendingDev{reinterpret_cast<void**>(const_cast<T**>(out)), v.empty() ? nullptr : (const void*)v.data(),
+                                  std::max<size_t>(v.size(), 1) * sizeof(T)});
+}
+int env_int(const char* name, int dflt);
+// One allocation for every array of `todo`, pointers handed out, uploads copied.  Touches no handle (it also runs on
+// ba_set_problem's helper thread); *base_out is the allocation (to be freed by the caller's owner) or null.
+hipError_t commit_list(const std::vector<PendingDev>& todo, void** base_out) {
+  constexpr size_t ALIGN = 256, SMALL = 64 * 1024;
+  *base_out = nullptr;
+  auto padded = [](size_t b) { return (b + ALIGN - 1) / ALIGN * ALIGN; };
+  // small uploads first and contiguous (one staging copy), then the large uploads, then what is only allocated
+  auto cls = [&](const PendingDev& q) { return q.src == nullptr ? 2 : (q.bytes <= SMALL ? 0 : 1); };
+  std::vector<size_t> off(todo.size());
+  size_t total = 0, small_bytes = 0;
+  for (int c = 0; c < 3; ++c) {
+    for (size_t i = 0; i < todo.size(); ++i)
+      if (cls(todo[i]) == c) { off[i] = total; total += padded(todo[i].bytes); }
+    if (c == 0) small_bytes = total;
+  }
+  if (total == 0) return hipSuccess;
+  void* base = nullptr;
+  const auto t_a = clk::now();
+  hipError_t e = hipMalloc(&base, total);
+  if (e != hipSuccess) return e;
+  if (env_int("BA_SETUP_TRACE", 0)) std::fprintf(stderr, "[ba_set_problem]   hipMalloc of %.1f MB %8.3f ms\n", total / 1048576.0, ms_since(t_a));
+  *base_out = base;
+  char* b = static_cast<char*>(base);
+  for (size_t i = 0; i < todo.size(); ++i) *todo[i].out = b + off[i];
+  if (small_bytes > 0) {
+    std::vector<char> staging(small_bytes, 0);
+    for (size_t i = 0; i < todo.size(); ++i)
+      if (cls(todo[i]) == 0) std::memcpy(staging.data() + off[i], todo[i].src, todo[i].bytes);
+    if ((e = hipMemcpy(b, staging.data(), small_bytes, hipMemcpyHostToDevice)) != hipSuccess) return e;
+  }
+  for (size_t i = 0; i < todo.size(); ++i)
+    if (cls(todo[i]) == 1 && (e = hipMemcpy(b + off[i], todo[i].src, todo[i].bytes, hipMemcpyHostToDevice)) != hipSuccess) return e;
+  return hipSuccess;
+}
+int dev_commit(ba_handle* h) {
+  std::vector<PendingDev> todo;
+  todo.swap(h->pending);
+  void* base = nullptr;
+  const hipError_t e = commit_list(todo, &base);
+  if (base) h->allocs.push_back(base);
+  HIP_TRY(h, e);
   return BA_OK;
 }
 
@@ -1066,6 +1149,13 @@ int ba_comm_init(ba_handle* h, int32_t rank, int32_t world, const char* id128) {
   return BA_OK;
 }
 
+int ba_debug_table_digests(const ba_handle* h, uint64_t* out, int32_t cap, int32_t* count) {
+  if (!h || !count || cap < 0 || (cap > 0 && !out)) return BA_ERR_INVALID;
+  *count = (int32_t)h->table_digests.size();
+  for (int32_t i = 0; i < std::min(cap, *count); ++i) out[i] = h->table_digests[(size_t)i];
+  return BA_OK;
+}
+
 int ba_comm_info(const ba_handle* h, int32_t* rank, int32_t* world) {
   if (!h || !rank || !world) return BA_ERR_INVALID;
   *rank = 0;
@@ -1122,11 +1212,23 @@ int validate_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
   for (int i = 0; i < 7; ++i)
     if (!std::isfinite(intr[i])) return fail(h, BA_ERR_INVALID, "intrinsics[%d] is not finite", i);
   if (!(intr[0] > 0) || !(intr[1] > 0)) return fail(h, BA_ERR_INVALID, "focal lengths must be positive");
-  for (int k = 0; k < n; ++k) {
-    if (obs_cam[k] < 0 || obs_cam[k] >= C) return fail(h, BA_ERR_INVALID, "obs_cam[%d]=%d out of range", k, obs_cam[k]);
-    if (obs_pt[k] < 0 || obs_pt[k] >= L) return fail(h, BA_ERR_INVALID, "obs_pt[%d]=%d out of range", k, obs_pt[k]);
-    if (!std::isfinite(obs_uv[2 * (size_t)k]) || !std::isfinite(obs_uv[2 * (size_t)k + 1]))
+  {
+    // the first observation that is wrong, if any (ranges of the list on host threads; the smallest index wins, as a
+    // plain loop would report it)
+    const int T = hostpar::threads_for(n, 65536);
+    std::vector<long> first_bad((size_t)T, -1);
+    hostpar::run(T, [&](int t, int nt) {
+      for (long k = hostpar::part_begin(n, t, nt); k < hostpar::part_begin(n, t + 1, nt); ++k)
+        if (obs_cam[k] < 0 || obs_cam[k] >= C || obs_pt[k] < 0 || obs_pt[k] >= L || !std::isfinite(obs_uv[2 * (size_t)k]) ||
+            !std::isfinite(obs_uv[2 * (size_t)k + 1])) { first_bad[(size_t)t] = k; break; }
+    });
+    for (long kb : first_bad) {
+      if (kb < 0) continue;
+      const int k = (int)kb;
+      if (obs_cam[k] < 0 || obs_cam[k] >= C) return fail(h, BA_ERR_INVALID, "obs_cam[%d]=%d out of range", k, obs_cam[k]);
+      if (obs_pt[k] < 0 || obs_pt[k] >= L) return fail(h, BA_ERR_INVALID, "obs_pt[%d]=%d out of range", k, obs_pt[k]);
       return fail(h, BA_ERR_INVALID, "observation %d is not finite", k);
+    }
   }
   if (!h->prior.cams.empty()) {
     if (h->world > 1) return fail(h, BA_ERR_STATE, "set_problem: a pose prior is set, which several ranks do not support");
@@ -1207,9 +1309,21 @@ namespace {
 int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t* obs_cam, const int32_t* obs_pt,
                      const double* obs_uv, const double* intr, const uint8_t* fixed_in) {
   const auto t0 = clk::now();
+  // BA_SETUP_TRACE=1: wall time of every stage of the set-up to stderr
+  const bool trace = env_int("BA_SETUP_TRACE", 0) != 0;
+  auto t_lap = t0;
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    const auto now = clk::now();
+    std::fprintf(stderr, "[ba_set_problem] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_lap).count());
+    t_lap = now;
+  };
   HIP_TRY(h, hipSetDevice(h->device));
   free_problem(h);
   h->C = C; h->L = L; h->n = n;
+  h->digest_on = env_int("BA_TABLE_DIGEST", 0) != 0;
+  h->table_digests.clear();
+  lap("free the previous problem");
 
   // ---- cameras
   h->fixed.assign(C, 0);
@@ -1222,61 +1336,133 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
   if (h->Cf == 0) return fail(h, BA_ERR_INVALID, "every pose is fixed: nothing to optimise");
   const int Cf = h->Cf;
 
-  // ---- tracks: observations grouped by landmark, camera-sorted inside a track
-  std::vector<int> cnt(L + 1, 0);
-  for (int k = 0; k < n; ++k) cnt[obs_pt[k] + 1]++;
+  // ---- tracks: observations grouped by landmark, camera-sorted inside a track.  On host threads: every thread owns a
+  //      range of landmarks and scans the observation list for them (a counting sort without shared counters)
   std::vector<int> uptr(L + 1, 0);
-  for (int j = 0; j < L; ++j) uptr[j + 1] = uptr[j] + cnt[j + 1];
-  std::vector<int> track(n);
+  hostpar::raw_vector<int> track(n);
   {
-    std::vector<int> fill(uptr.begin(), uptr.end() - 1);
-    for (int k = 0; k < n; ++k) track[fill[obs_pt[k]]++] = k;
-  }
-  for (int j = 0; j < L; ++j)
-    std::sort(track.begin() + uptr[j], track.begin() + uptr[j + 1], [&](int a, int b) {
-      return obs_cam[a] != obs_cam[b] ? obs_cam[a] < obs_cam[b] : a < b;
+    const int T = hostpar::threads_for(n);
+    std::vector<int> cnt(L + 1, 0);
+    hostpar::for_range(L, T, [&](long l0, long l1) {
+      if (T == 1) { for (int k = 0; k < n; ++k) cnt[obs_pt[k] + 1]++; return; }
+      for (int k = 0; k < n; ++k) { const int j = obs_pt[k]; if (j >= l0 && j < l1) cnt[j + 1]++; }
     });
+    for (int j = 0; j < L; ++j) uptr[j + 1] = uptr[j] + cnt[j + 1];
+    std::vector<int>& fill = cnt;  // reused: next free entry of every track
+    hostpar::for_range(L, T, [&](long l0, long l1) {
+      for (long j = l0; j < l1; ++j) fill[j] = uptr[j];
+      if (T == 1) { for (int k = 0; k < n; ++k) track[fill[obs_pt[k]]++] = k; }
+      else for (int k = 0; k < n; ++k) { const int j = obs_pt[k]; if (j >= l0 && j < l1) track[fill[j]++] = k; }
+      for (long j = l0; j < l1; ++j) {
+        int* b = track.data() + uptr[j];
+        int* e = track.data() + uptr[j + 1];
+        // entries arrive in ascending k: image-major input (the reference's packing order, bundle_adjustment.py:178-194)
+        // is camera-sorted already
+        bool sorted = true;
+        for (int* q = b; q + 1 < e; ++q)
+          if (obs_cam[q[0]] > obs_cam[q[1]]) { sorted = false; break; }
+        if (!sorted) std::sort(b, e, [&](int a, int c2) { return obs_cam[a] != obs_cam[c2] ? obs_cam[a] < obs_cam[c2] : a < c2; });
+      }
+    });
+  }
+  lap("tracks");
   // ---- landmark order: observed first, lexicographic by camera signature (locality for the
-  //      register run-length accumulation of k_linearize / k_schur), ties by index
+  //      register run-length accumulation of k_linearize / k_schur), ties by index.  Sorted by a 64-bit key that packs
+  //      the first cameras of the signature (camera + 1 per field, 0 = past the end of the track, so that a signature
+  //      which is a prefix of another sorts first, as comparing the lengths would have it); the rest of a long signature
+  //      is looked at only between equal keys
   std::vector<int> order(L);
-  std::iota(order.begin(), order.end(), 0);
-  auto sig_less = [&](int a, int b) {
-    const int la = uptr[a + 1] - uptr[a], lb = uptr[b + 1] - uptr[b];
-    if ((la == 0) != (lb == 0)) return lb == 0;
-    const int m = std::min(la, lb);
-    for (int i = 0; i < m; ++i) {
-      const int ca = obs_cam[track[uptr[a] + i]], cb = obs_cam[track[uptr[b] + i]];
-      if (ca != cb) return ca < cb;
+  int L_obs = 0;
+  {
+    int bits = 1;
+    while (((long)C >> bits) != 0) ++bits;  // camera + 1 <= C needs `bits` bits
+    const int slots = 64 / bits;
+    struct Key { uint64_t key; int idx; };
+    for (int j = 0; j < L; ++j) L_obs += uptr[j + 1] > uptr[j] ? 1 : 0;
+    std::vector<Key> keyed((size_t)L_obs);
+    {
+      int a = 0, b = L_obs;  // observed landmarks to the front (sorted below), the others behind them in index order
+      for (int j = 0; j < L; ++j) {
+        if (uptr[j + 1] > uptr[j]) keyed[(size_t)a++].idx = j;
+        else order[b++] = j;
+      }
     }
-    if (la != lb) return la < lb;
-    return a < b;
-  };
-  std::sort(order.begin(), order.end(), sig_less);
+    const int T = hostpar::threads_for(L_obs, 8192);
+    hostpar::for_range(L_obs, T, [&](long i0, long i1) {
+      for (long i = i0; i < i1; ++i) {
+        const int j = keyed[(size_t)i].idx, len = uptr[j + 1] - uptr[j];
+        uint64_t key = 0;
+        for (int q = 0; q < slots; ++q) key = (key << bits) | (q < len ? (uint64_t)(obs_cam[track[uptr[j] + q]] + 1) : 0u);
+        keyed[(size_t)i].key = key;
+      }
+    });
+    auto key_less = [&](const Key& x, const Key& y) {
+      if (x.key != y.key) return x.key < y.key;
+      const int a = x.idx, b = y.idx;
+      const int la = uptr[a + 1] - uptr[a], lb = uptr[b + 1] - uptr[b];
+      const int m = std::min(la, lb);
+      for (int i = slots; i < m; ++i) {
+        const int ca = obs_cam[track[uptr[a] + i]], cb = obs_cam[track[uptr[b] + i]];
+        if (ca != cb) return ca < cb;
+      }
+      if (la > slots || lb > slots) { if (la != lb) return la < lb; }
+      return a < b;
+    };
+    hostpar::sort(keyed, key_less, T);
+    hostpar::for_range(L_obs, T, [&](long i0, long i1) { for (long i = i0; i < i1; ++i) order[i] = keyed[(size_t)i].idx; });
+  }
   h->lm_internal_to_user = order;
   h->lm_user_to_internal.assign(L, 0);
   for (int j = 0; j < L; ++j) h->lm_user_to_internal[order[j]] = j;
-  int L_obs = 0;
-  while (L_obs < L && uptr[order[L_obs] + 1] > uptr[order[L_obs]]) ++L_obs;
   h->L_obs = L_obs;
+  lap("landmark order");
 
-  std::vector<int> o_cam(n), o_src(n), o_lm(n), lm_ptr(L_obs + 1, 0);
-  std::vector<double> o_u(n), o_v(n);
+  hostpar::raw_vector<int> o_cam(n), o_src(n), o_lm(n), o_free(n);  // written in full below, by the threads that first touch them
+  hostpar::raw_vector<double> o_u(n), o_v(n);
+  std::vector<int> lm_ptr(L_obs + 1, 0);
   {
-    int k2 = 0;
-    for (int j = 0; j < L_obs; ++j) {
-      const int uj = order[j];
-      for (int e = uptr[uj]; e < uptr[uj + 1]; ++e, ++k2) {
-        const int k = track[e];
-        o_cam[k2] = obs_cam[k]; o_src[k2] = k; o_lm[k2] = j;
-        o_u[k2] = obs_uv[2 * (size_t)k]; o_v[k2] = obs_uv[2 * (size_t)k + 1];
+    for (int j = 0; j < L_obs; ++j) lm_ptr[j + 1] = lm_ptr[j] + (uptr[order[j] + 1] - uptr[order[j]]);
+    hostpar::for_range(L_obs, hostpar::threads_for(n), [&](long j0, long j1) {
+      for (long j = j0; j < j1; ++j) {
+        const int uj = order[j];
+        int k2 = lm_ptr[j];
+        for (int e = uptr[uj]; e < uptr[uj + 1]; ++e, ++k2) {
+          const int k = track[e];
+          o_cam[k2] = obs_cam[k]; o_src[k2] = k; o_lm[k2] = (int)j;
+          o_u[k2] = obs_uv[2 * (size_t)k]; o_v[k2] = obs_uv[2 * (size_t)k + 1];
+          o_free[k2] = h->cam2free[obs_cam[k]];
+        }
       }
-      lm_ptr[j + 1] = k2;
-    }
+    });
   }
-  h->obs_src = o_src;
-  std::vector<int> o_free(n);
-  for (int k = 0; k < n; ++k) o_free[k] = h->cam2free[o_cam[k]];
-
+  h->obs_src.assign(o_src.begin(), o_src.end());
+  lap("observation arrays");
+  // The per-observation arrays are the bulk of what goes to the device.  Their allocation and their (blocking, pageable)
+  // copies run on a helper thread from here on, beside the construction of the tables below; joined after dev_commit.
+  // The thread writes six pointers of h->d that nobody reads before the join, and nothing else of the handle.
+  struct EarlyUpload {
+    std::thread th;
+    void* base = nullptr;
+    hipError_t err = hipSuccess;
+    bool kept = false;
+    ~EarlyUpload() {
+      if (th.joinable()) th.join();
+      if (base && !kept) (void)hipFree(base);
+    }
+  } early;
+  {
+    h->pending.clear();
+    queue_upload(h, &h->d.o_cam, o_cam); queue_upload(h, &h->d.o_u, o_u); queue_upload(h, &h->d.o_v, o_v);
+    queue_upload(h, &h->d.o_src, o_src); queue_upload(h, &h->d.o_lm, o_lm); queue_upload(h, &h->d.o_free, o_free);
+    auto list = std::make_shared<std::vector<PendingDev>>();
+    list->swap(h->pending);
+    EarlyUpload* eu = &early;
+    const int dev = h->device;
+    early.th = std::thread([list, eu, dev] {
+      if ((eu->err = hipSetDevice(dev)) != hipSuccess) return;
+      eu->err = commit_list(*list, &eu->base);
+    });
+  }
   // ---- block pattern of the reduced camera system (upper triangle over free cameras)
   std::vector<int64_t> keys;
   for (int f = 0; f < Cf; ++f) keys.push_back((int64_t)f * Cf + f);
@@ -1286,22 +1472,32 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
       if (fa < fb) keys.push_back((int64_t)fa * Cf + fb);
     }
   {
-    std::vector<int> prev, cur;
-    for (int j = 0; j < L_obs; ++j) {
-      cur.clear();
-      for (int k = lm_ptr[j]; k < lm_ptr[j + 1]; ++k) {
-        const int f = h->cam2free[o_cam[k]];
-        if (f >= 0 && (cur.empty() || cur.back() != f)) cur.push_back(f);
+    // pairs of free cameras that share a landmark: landmark ranges on host threads, each with its own key list (runs of
+    // landmarks with one signature contribute once), then one sorted, duplicate-free list: whatever the cut, the same list
+    const int T = hostpar::threads_for(n, 65536);
+    std::vector<std::vector<int64_t>> part((size_t)T);
+    hostpar::run(T, [&](int t, int nt) {
+      std::vector<int64_t>& out = part[(size_t)t];
+      std::vector<int> prev, cur;
+      for (long j = hostpar::part_begin(L_obs, t, nt); j < hostpar::part_begin(L_obs, t + 1, nt); ++j) {
+        cur.clear();
+        for (int k = lm_ptr[j]; k < lm_ptr[j + 1]; ++k) {
+          const int f = o_free[k];
+          if (f >= 0 && (cur.empty() || cur.back() != f)) cur.push_back(f);
+        }
+        if (cur == prev) continue;
+        for (size_t a = 0; a < cur.size(); ++a)
+          for (size_t b = a + 1; b < cur.size(); ++b) out.push_back((int64_t)cur[a] * Cf + cur[b]);
+        prev.swap(cur);
+        if (out.size() > ((size_t)64 << 20) / (size_t)nt) {  // keep the key lists bounded on unstructured scenes
+          std::sort(out.begin(), out.end());
+          out.erase(std::unique(out.begin(), out.end()), out.end());
+        }
       }
-      if (cur == prev) continue;
-      for (size_t a = 0; a < cur.size(); ++a)
-        for (size_t b = a + 1; b < cur.size(); ++b) keys.push_back((int64_t)cur[a] * Cf + cur[b]);
-      prev.swap(cur);
-      if (keys.size() > (size_t)64 << 20) {  // keep the key list bounded on unstructured scenes
-        std::sort(keys.begin(), keys.end());
-        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
-      }
-    }
+      std::sort(out.begin(), out.end());
+      out.erase(std::unique(out.begin(), out.end()), out.end());
+    });
+    for (auto& v : part) keys.insert(keys.end(), v.begin(), v.end());
   }
   std::sort(keys.begin(), keys.end());
   keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
@@ -1380,6 +1576,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
     return da != db ? da < db : urow[a] < urow[b];
   });
 
+  lap("block pattern");
   // ---- launch geometry
   {
     std::vector<int> lens(L_obs);
@@ -1438,37 +1635,54 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
   if (h->lin_win || h->lin_rows) {
     const int nwg = (h->flat_chunks + LINF_WAVES - 1) / LINF_WAVES;
     if (h->lin_win) lin_wincam.assign((size_t)nwg * LINW_WIN, -1);
-    std::vector<int> idx;
-    for (int wg = 0; wg < nwg; ++wg) {
-      int* win = h->lin_win ? lin_wincam.data() + (size_t)wg * LINW_WIN : nullptr;
-      int nwin = 0;
-      for (int c = wg * LINF_WAVES; c < std::min(h->flat_chunks, (wg + 1) * LINF_WAVES); ++c) {
-        const int kb = lin_k[c], ke = lin_k[c + 1];
-        idx.clear();
-        for (int k = kb; k < ke; ++k)
-          if (o_free[k] >= 0) idx.push_back(k);
-        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return o_cam[a] < o_cam[b]; });
-        {  // observations of fixed cameras take the rows after the free ones (their products are zero, nobody sums them)
-          size_t tail = idx.size();
+    // workgroups are independent: ranges of them on host threads, each with its own piece of the group tables
+    struct Piece { std::vector<int> gbeg, gcam, gslot, gend; };
+    const int T = hostpar::threads_for(n, 16384);
+    std::vector<Piece> piece((size_t)T);
+    hostpar::run(T, [&](int t, int nt) {
+      Piece& pc = piece[(size_t)t];
+      std::vector<int> idx;
+      for (int wg = (int)hostpar::part_begin(nwg, t, nt); wg < (int)hostpar::part_begin(nwg, t + 1, nt); ++wg) {
+        int* win = h->lin_win ? lin_wincam.data() + (size_t)wg * LINW_WIN : nullptr;
+        int nwin = 0;
+        for (int c = wg * LINF_WAVES; c < std::min(h->flat_chunks, (wg + 1) * LINF_WAVES); ++c) {
+          const int kb = lin_k[c], ke = lin_k[c + 1];
+          idx.clear();
           for (int k = kb; k < ke; ++k)
-            if (o_free[k] < 0) lin_perm[k] = (unsigned char)tail++;
-        }
-        for (size_t p2 = 0; p2 < idx.size(); ++p2) {
-          lin_perm[idx[p2]] = (unsigned char)p2;
-          if (p2 == 0 || o_cam[idx[p2]] != o_cam[idx[p2 - 1]]) {
-            const int cam = o_cam[idx[p2]];
-            int slot = -1;
-            if (win) {
-              for (int s2 = 0; s2 < nwin; ++s2)
-                if (win[s2] == cam) slot = s2;
-              if (slot < 0 && nwin < LINW_WIN) { slot = nwin; win[nwin++] = cam; }
-            }
-            lin_gbeg.push_back((int)p2); lin_gcam.push_back(cam); lin_gslot.push_back(slot);
+            if (o_free[k] >= 0) idx.push_back(k);
+          std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return o_cam[a] < o_cam[b]; });
+          {  // observations of fixed cameras take the rows after the free ones (their products are zero, nobody sums them)
+            size_t tail = idx.size();
+            for (int k = kb; k < ke; ++k)
+              if (o_free[k] < 0) lin_perm[k] = (unsigned char)tail++;
           }
+          for (size_t p2 = 0; p2 < idx.size(); ++p2) {
+            lin_perm[idx[p2]] = (unsigned char)p2;
+            if (p2 == 0 || o_cam[idx[p2]] != o_cam[idx[p2 - 1]]) {
+              const int cam = o_cam[idx[p2]];
+              int slot = -1;
+              if (win) {
+                for (int s2 = 0; s2 < nwin; ++s2)
+                  if (win[s2] == cam) slot = s2;
+                if (slot < 0 && nwin < LINW_WIN) { slot = nwin; win[nwin++] = cam; }
+              }
+              pc.gbeg.push_back((int)p2); pc.gcam.push_back(cam); pc.gslot.push_back(slot);
+            }
+          }
+          pc.gbeg.push_back((int)idx.size()); pc.gcam.push_back(-1); pc.gslot.push_back(-1);  // sentinel
+          pc.gend.push_back((int)pc.gbeg.size());
         }
-        lin_gbeg.push_back((int)idx.size()); lin_gcam.push_back(-1); lin_gslot.push_back(-1);  // sentinel
-        lin_gptr.push_back((int)lin_gbeg.size());
       }
+    });
+    size_t total = 0;
+    for (const Piece& pc : piece) total += pc.gbeg.size();
+    lin_gbeg.reserve(total); lin_gcam.reserve(total); lin_gslot.reserve(total); lin_gptr.reserve((size_t)h->flat_chunks + 1);
+    for (const Piece& pc : piece) {
+      const int base = (int)lin_gbeg.size();
+      lin_gbeg.insert(lin_gbeg.end(), pc.gbeg.begin(), pc.gbeg.end());
+      lin_gcam.insert(lin_gcam.end(), pc.gcam.begin(), pc.gcam.end());
+      lin_gslot.insert(lin_gslot.end(), pc.gslot.begin(), pc.gslot.end());
+      for (int e : pc.gend) lin_gptr.push_back(base + e);
     }
   }
   if (h->lin_rows) {
@@ -1495,6 +1709,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
     }
     ucr_ptr[(size_t)C * rows_nslab] = per_cam[C];
   }
+  lap("linearize tables");
   // ---- k_schur_staged tables: chunks (consecutive landmarks, <= SCH_CAP observations, <= SCH_MAXLM
   // landmarks), the steps at which a wave must write its accumulators out (some lane's camera pair
   // changes), the contribution rows those write-outs fill, and the inverted index S block -> rows.
@@ -1527,48 +1742,78 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
       for (int b2 = 0, p = 0; p < 64; ++b2)
         for (int a2 = 0; a2 <= b2 && p < 64; ++a2, ++p) { pa[p] = a2; pb[p] = b2; }
       struct Cur { int fa, fb; bool sym; };
-      std::vector<std::pair<int, int>> contributors;  // (upper slot, contribution row)
       auto slot_of = [&](int fa, int fb) {
         const int* lo = ucol.data() + urow_ptr[fa];
         const int* hi = ucol.data() + urow_ptr[fa + 1];
         return (int)(std::lower_bound(lo, hi, fb) - ucol.data());
       };
-      for (int blk = 0; blk < n_blocks; ++blk) {
-        Cur cur[64];
-        for (auto& c : cur) c = Cur{-1, -1, false};
-        sch_blk_row.push_back((int)contrib_rows);
-        auto write_out = [&]() {
-          for (int lane = 0; lane < 64; ++lane)
-            if (cur[lane].fa >= 0) {
-              contributors.emplace_back(slot_of(cur[lane].fa, cur[lane].fb), (int)(contrib_rows + lane));
-              cur[lane] = Cur{-1, -1, false};
-            }
-          contrib_rows += 64;
-        };
-        for (int ci = blk * cpb; ci < std::min(n_chunks, (blk + 1) * cpb); ++ci) {
-          const int jc = sch_lm[ci], nc = sch_lm[ci + 1] - jc;
-          for (int l0 = 0, step = 0; l0 < nc; l0 += GPW, ++step) {
-            Cur nxt[64];
-            bool need = false;
-            for (int lane = 0; lane < 64; ++lane) {
-              nxt[lane] = Cur{-1, -1, false};
-              const int grp = lane / G, gl = lane % G, li = l0 + grp;
-              if (li >= nc) continue;
-              const int kb = lm_ptr[jc + li], len = lm_ptr[jc + li + 1] - kb;
-              if (gl >= len * (len + 1) / 2) continue;
-              const int fa = o_free[kb + pa[gl]], fb = o_free[kb + pb[gl]];
-              if (fa < 0 || fb < 0) continue;
-              nxt[lane] = Cur{fa, fb, fa == fb && pa[gl] != pb[gl]};
-              if (cur[lane].fa >= 0 && (cur[lane].fa != fa || cur[lane].fb != fb || cur[lane].sym != nxt[lane].sym))
-                need = true;
-            }
-            if (need) { sch_flush[ci] |= 1u << step; write_out(); }
+      // blocks are independent but for the number of their first contribution row: ranges of blocks on host threads,
+      // rows counted from the start of the range, shifted once the ranges before it are known
+      struct Piece { std::vector<std::pair<int, int>> contributors; std::vector<long> blk_row; long rows = 0; };
+      const int T = hostpar::threads_for(n, 16384);
+      std::vector<Piece> piece((size_t)T);
+      hostpar::run(T, [&](int t, int nt) {
+        Piece& pc = piece[(size_t)t];
+        long rows = 0;
+        for (int blk = (int)hostpar::part_begin(n_blocks, t, nt); blk < (int)hostpar::part_begin(n_blocks, t + 1, nt); ++blk) {
+          Cur cur[64];
+          for (auto& c : cur) c = Cur{-1, -1, false};
+          pc.blk_row.push_back(rows);
+          auto write_out = [&]() {
             for (int lane = 0; lane < 64; ++lane)
-              if (nxt[lane].fa >= 0) cur[lane] = nxt[lane];
+              if (cur[lane].fa >= 0) {
+                pc.contributors.emplace_back(slot_of(cur[lane].fa, cur[lane].fb), (int)(rows + lane));
+                cur[lane] = Cur{-1, -1, false};
+              }
+            rows += 64;
+          };
+          for (int ci = blk * cpb; ci < std::min(n_chunks, (blk + 1) * cpb); ++ci) {
+            const int jc = sch_lm[ci], nc = sch_lm[ci + 1] - jc;
+            for (int l0 = 0, step = 0; l0 < nc; l0 += GPW, ++step) {
+              Cur nxt[64];
+              bool need = false;
+              for (int lane = 0; lane < 64; ++lane) {
+                nxt[lane] = Cur{-1, -1, false};
+                const int grp = lane / G, gl = lane % G, li = l0 + grp;
+                if (li >= nc) continue;
+                const int kb = lm_ptr[jc + li], len = lm_ptr[jc + li + 1] - kb;
+                if (gl >= len * (len + 1) / 2) continue;
+                const int fa = o_free[kb + pa[gl]], fb = o_free[kb + pb[gl]];
+                if (fa < 0 || fb < 0) continue;
+                nxt[lane] = Cur{fa, fb, fa == fb && pa[gl] != pb[gl]};
+                if (cur[lane].fa >= 0 && (cur[lane].fa != fa || cur[lane].fb != fb || cur[lane].sym != nxt[lane].sym))
+                  need = true;
+              }
+              if (need) { sch_flush[ci] |= 1u << step; write_out(); }
+              for (int lane = 0; lane < 64; ++lane)
+                if (nxt[lane].fa >= 0) cur[lane] = nxt[lane];
+            }
           }
+          write_out();  // the kernel always ends with one
+          if (rows > ((long)1 << 31)) break;  // too many rows for the staged path (decided below): no point in going on
         }
-        write_out();  // the kernel always ends with one
-        if (contrib_rows > ((long)1 << 31) - 128) break;
+        pc.rows = rows;
+      });
+      std::vector<std::pair<int, int>> contributors;  // (upper slot, contribution row)
+      {
+        std::vector<long> base((size_t)T + 1, 0);
+        size_t n_contrib = 0;
+        for (int t = 0; t < T; ++t) { base[(size_t)t + 1] = base[(size_t)t] + piece[(size_t)t].rows; n_contrib += piece[(size_t)t].contributors.size(); }
+        contrib_rows = base[(size_t)T];
+        if (contrib_rows <= ((long)1 << 31) - 128) {
+          contributors.resize(n_contrib);
+          std::vector<size_t> cbase((size_t)T + 1, 0);
+          for (int t = 0; t < T; ++t) cbase[(size_t)t + 1] = cbase[(size_t)t] + piece[(size_t)t].contributors.size();
+          sch_blk_row.reserve((size_t)n_blocks);
+          for (int t = 0; t < T; ++t)
+            for (long r : piece[(size_t)t].blk_row) sch_blk_row.push_back((int)(base[(size_t)t] + r));
+          hostpar::run(T, [&](int t, int) {
+            const Piece& pc = piece[(size_t)t];
+            const int shift = (int)base[(size_t)t];
+            for (size_t i = 0; i < pc.contributors.size(); ++i)
+              contributors[cbase[(size_t)t] + i] = {pc.contributors[i].first, pc.contributors[i].second + shift};
+          });
+        }
       }
       const long max_rows = ((long)env_int("BA_CONTRIB_MAX_MB", 16384) << 20) / (CTR_ROW * (long)sizeof(double));
       if (contrib_rows <= std::min<long>(max_rows, ((long)1 << 31) - 128)) {
@@ -1588,6 +1833,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
       }
     }
   }
+  lap("schur tables");
   // W is not stored when both of its readers can rebuild it (the staged Schur kernel and the flat back-substitution)
   // and the problem is large enough for the traffic to matter: measured per LM iteration, stored / rebuilt: config 2
   // (0.2 M observations) 135 / 137 us, config 3 (1 M) 395 / 398 us, config 4 (10 M) 1.89 / 1.76 ms (the linearisation
@@ -1977,6 +2223,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
                                      (int)h->comp_lds));
   }
 
+  lap("solver plans");
   // ---- upload structure, allocate state
   std::vector<int> fixed_cams;
   for (int c = 0; c < C; ++c)
@@ -2002,54 +2249,53 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
     HIP_TRY(h, hipFuncSetAttribute((const void*)k_linearize_flat<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
   int rc;
-  if ((rc = dev_upload(h, &d.o_cam, o_cam)) || (rc = dev_upload(h, &d.o_u, o_u)) || (rc = dev_upload(h, &d.o_v, o_v)) ||
-      (rc = dev_upload(h, &d.o_src, o_src)) || (rc = dev_upload(h, &d.o_lm, o_lm)) ||
-      (rc = dev_upload(h, &d.o_free, o_free)) ||
-      (rc = dev_upload(h, &d.lm_ptr, lm_ptr)) || (rc = dev_upload(h, &d.cam2free, h->cam2free)) ||
-      (rc = dev_upload(h, &d.free2cam, h->free2cam)) || (rc = dev_upload(h, &d.fixed_cams, fixed_cams)) || (rc = dev_upload(h, &d.urow_ptr, urow_ptr)) ||
-      (rc = dev_upload(h, &d.ucol, ucol)) || (rc = dev_upload(h, &d.urow, urow)) ||
-      (rc = dev_upload(h, &d.diag_slot, diag_slot)) || (rc = dev_upload(h, &d.low_of, low_of)) ||
-      (rc = dev_upload(h, &d.brow_ptr, brow_ptr)) || (rc = dev_upload(h, &d.bcol, bcol)) ||
-      (rc = dev_upload(h, &d.bslot, bslot)) || (rc = dev_upload(h, &d.sm_slot, sm_slot)) ||
-      (rc = dev_upload(h, &d.sm_desc, sm_desc)) ||
-      (rc = dev_upload(h, &d.sm_gidx, sm_gidx)) ||
-      (rc = dev_upload(h, &d.comp_ptr, comp_ptr)) || (rc = dev_upload(h, &d.comp_cams, comp_cams)) ||
-      (rc = dev_upload(h, &d.comp_local, comp_local)) || (rc = dev_upload(h, &d.comp_slot_ptr, comp_slot_ptr)) ||
-      (rc = dev_upload(h, &d.comp_slots, comp_slots)) ||
-      (rc = dev_upload(h, &d.lin_lm, lin_lm)) || (rc = dev_upload(h, &d.lin_k, lin_k)) ||
-      (rc = dev_upload(h, &d.lin_perm, lin_perm)) || (rc = dev_upload(h, &d.lin_gptr, lin_gptr)) ||
-      (rc = dev_upload(h, &d.lin_gbeg, lin_gbeg)) || (rc = dev_upload(h, &d.lin_gcam, lin_gcam)) ||
-      (rc = dev_upload(h, &d.lin_gslot, lin_gslot)) || (rc = dev_upload(h, &d.lin_wincam, lin_wincam)) ||
-      (rc = dev_upload(h, &d.ucr_ptr, ucr_ptr)) || (rc = dev_upload(h, &d.ucr_row, ucr_row)) ||
-      (rc = dev_upload(h, &d.sch_lm, sch_lm)) || (rc = dev_upload(h, &d.sch_k, sch_k)) ||
-      (rc = dev_upload(h, &d.sch_flush, sch_flush)) || (rc = dev_upload(h, &d.sch_blk_row, sch_blk_row)) ||
-      (rc = dev_upload(h, &d.ctr_ptr, ctr_ptr)) || (rc = dev_upload(h, &d.ctr_row, ctr_row)) ||
-      (rc = dev_alloc(h, &d.contrib, (size_t)contrib_rows * CTR_ROW)))
-    return rc;
+  h->pending.clear();
+  queue_upload(h, &d.lm_ptr, lm_ptr); queue_upload(h, &d.cam2free, h->cam2free);
+  queue_upload(h, &d.free2cam, h->free2cam); queue_upload(h, &d.fixed_cams, fixed_cams); queue_upload(h, &d.urow_ptr, urow_ptr);
+  queue_upload(h, &d.ucol, ucol); queue_upload(h, &d.urow, urow);
+  queue_upload(h, &d.diag_slot, diag_slot); queue_upload(h, &d.low_of, low_of);
+  queue_upload(h, &d.brow_ptr, brow_ptr); queue_upload(h, &d.bcol, bcol);
+  queue_upload(h, &d.bslot, bslot); queue_upload(h, &d.sm_slot, sm_slot);
+  queue_upload(h, &d.sm_desc, sm_desc);
+  queue_upload(h, &d.sm_gidx, sm_gidx);
+  queue_upload(h, &d.comp_ptr, comp_ptr); queue_upload(h, &d.comp_cams, comp_cams);
+  queue_upload(h, &d.comp_local, comp_local); queue_upload(h, &d.comp_slot_ptr, comp_slot_ptr);
+  queue_upload(h, &d.comp_slots, comp_slots);
+  queue_upload(h, &d.lin_lm, lin_lm); queue_upload(h, &d.lin_k, lin_k);
+  queue_upload(h, &d.lin_perm, lin_perm); queue_upload(h, &d.lin_gptr, lin_gptr);
+  queue_upload(h, &d.lin_gbeg, lin_gbeg); queue_upload(h, &d.lin_gcam, lin_gcam);
+  queue_upload(h, &d.lin_gslot, lin_gslot); queue_upload(h, &d.lin_wincam, lin_wincam);
+  queue_upload(h, &d.ucr_ptr, ucr_ptr); queue_upload(h, &d.ucr_row, ucr_row);
+  queue_upload(h, &d.sch_lm, sch_lm); queue_upload(h, &d.sch_k, sch_k);
+  queue_upload(h, &d.sch_flush, sch_flush); queue_upload(h, &d.sch_blk_row, sch_blk_row);
+  queue_upload(h, &d.ctr_ptr, ctr_ptr); queue_upload(h, &d.ctr_row, ctr_row);
+  queue_alloc(h, &d.contrib, (size_t)contrib_rows * CTR_ROW);
   d.W = nullptr;
-  if (!h->matrix_free && (rc = dev_alloc(h, &d.W, (size_t)W_ROWS * n))) return rc;
+  if (!h->matrix_free) queue_alloc(h, &d.W, (size_t)W_ROWS * n);
   d.n_urows = h->lin_rows ? (long)lin_gcam.size() : 0;
   d.n_bs_blocks = h->flat_chunks > 0 ? grid_for(h->flat_chunks, 4) : 0;
   d.n_pose_blocks = grid_for(C);
-  if ((rc = dev_alloc(h, &d.Urows, (size_t)27 * d.n_urows)) || (rc = dev_alloc(h, &d.lin_part, (size_t)4 * h->flat_chunks)) ||
-      (rc = dev_alloc(h, &d.bs_part, (size_t)8 * d.n_bs_blocks)) || (rc = dev_alloc(h, &d.pose_part, (size_t)5 * d.n_pose_blocks)))
-    return rc;
-  if ((rc = dev_alloc(h, &d.V, (size_t)6 * L)) ||
-      (rc = dev_alloc(h, &d.gp, (size_t)3 * L)) || (rc = dev_alloc(h, &d.zmin, (size_t)L)) ||
-      (rc = dev_alloc(h, &d.Ugc_part, (size_t)27 * C)) ||
-      (rc = dev_alloc(h, &d.S, (size_t)36 * (nu + gap_blocks + nl))) ||
-      (rc = dev_alloc(h, &h->scal_fold, (size_t)SC_COUNT + FOLD_MAX_RANKS)) ||
-      (rc = dev_alloc(h, &d.Ugc_slab, (size_t)nslab_u * 27 * C + (size_t)SC_COUNT * SCAL_SLABS +
-                                          (size_t)nslab_s * d.s_slab_stride)) ||
-      (rc = dev_alloc(h, &d.ctrl, 1)) ||
-      (rc = dev_alloc(h, &d.Minv, (size_t)36 * Cf)) ||
-      (rc = dev_alloc(h, &d.dc, (size_t)6 * Cf)) || (rc = dev_alloc(h, &d.r, (size_t)6 * Cf)) ||
-      (rc = dev_alloc(h, &d.z, (size_t)6 * Cf)) || (rc = dev_alloc(h, &d.p, (size_t)6 * Cf)) ||
-      (rc = dev_alloc(h, &d.q, (size_t)6 * Cf)) ||
-      (rc = dev_alloc(h, &d.poses_buf[0], (size_t)7 * C)) || (rc = dev_alloc(h, &d.poses_buf[1], (size_t)7 * C)) ||
-      (rc = dev_alloc(h, &h->poses_init, (size_t)7 * C)) || (rc = dev_alloc(h, &d.pts_buf[0], (size_t)3 * L)) ||
-      (rc = dev_alloc(h, &d.pts_buf[1], (size_t)3 * L)) || (rc = dev_alloc(h, &h->pts_init, (size_t)3 * L)))
-    return rc;
+  queue_alloc(h, &d.Urows, (size_t)27 * d.n_urows); queue_alloc(h, &d.lin_part, (size_t)4 * h->flat_chunks);
+  queue_alloc(h, &d.bs_part, (size_t)8 * d.n_bs_blocks); queue_alloc(h, &d.pose_part, (size_t)5 * d.n_pose_blocks);
+  queue_alloc(h, &d.V, (size_t)6 * L);
+  queue_alloc(h, &d.gp, (size_t)3 * L); queue_alloc(h, &d.zmin, (size_t)L);
+  queue_alloc(h, &d.Ugc_part, (size_t)27 * C);
+  queue_alloc(h, &d.S, (size_t)36 * (nu + gap_blocks + nl));
+  queue_alloc(h, &h->scal_fold, (size_t)SC_COUNT + FOLD_MAX_RANKS);
+  queue_alloc(h, &d.Ugc_slab, (size_t)nslab_u * 27 * C + (size_t)SC_COUNT * SCAL_SLABS + (size_t)nslab_s * d.s_slab_stride);
+  queue_alloc(h, &d.ctrl, 1);
+  queue_alloc(h, &d.Minv, (size_t)36 * Cf);
+  queue_alloc(h, &d.dc, (size_t)6 * Cf); queue_alloc(h, &d.r, (size_t)6 * Cf);
+  queue_alloc(h, &d.z, (size_t)6 * Cf); queue_alloc(h, &d.p, (size_t)6 * Cf);
+  queue_alloc(h, &d.q, (size_t)6 * Cf);
+  queue_alloc(h, &d.poses_buf[0], (size_t)7 * C); queue_alloc(h, &d.poses_buf[1], (size_t)7 * C);
+  queue_alloc(h, &h->poses_init, (size_t)7 * C); queue_alloc(h, &d.pts_buf[0], (size_t)3 * L);
+  queue_alloc(h, &d.pts_buf[1], (size_t)3 * L); queue_alloc(h, &h->pts_init, (size_t)3 * L);
+  if ((rc = dev_commit(h))) return rc;
+  early.th.join();
+  if (early.base) { h->allocs.push_back(early.base); early.kept = true; }
+  HIP_TRY(h, early.err);
+  lap("uploads + state allocation");
   h->banded_B = nullptr;
   if (h->banded_solve && h->bseg_P > 0) {
     if ((rc = dev_alloc(h, &h->banded_B, (size_t)h->bseg_total)) || (rc = dev_alloc(h, &h->bseg_x2, (size_t)6 * h->bshape.Cf)) ||
@@ -2121,6 +2367,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
     HIP_TRY(h, hipFuncSetAttribute((const void*)k_dense_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)((DPACK + 2 * DT) * sizeof(double))));
   }
+  lap("solver buffers");
   d.scal = d.Ugc_slab + (size_t)nslab_u * 27 * C;
   d.S_slab = d.scal + (size_t)SC_COUNT * SCAL_SLABS;
   HIP_TRY(h, hipMemset(d.ctrl, 0, sizeof(LmCtrl)));
@@ -2133,6 +2380,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
   h->stage_bytes = ((size_t)7 * C + (size_t)3 * L) * sizeof(double);
   HIP_TRY(h, hipHostMalloc((void**)&h->stage, h->stage_bytes));
   HIP_TRY(h, hipDeviceSynchronize());
+  lap("memsets + stage + sync");
   h->has_problem = true;
   h->setup_ms = ms_since(t0);
   return BA_OK;

@@ -90,6 +90,7 @@ _SIGNATURES = {
     "ba_comm_unique_id": (C.c_int, [C.c_char_p]),
     "ba_comm_init": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_char_p]),
     "ba_comm_info": (C.c_int, [_P, _I, _I]),
+    "ba_debug_table_digests": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int32, _I]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -227,6 +228,14 @@ class Solver:
         if len(unique_id) != 128:
             raise ValidationError("unique_id must be the 128 bytes of comm_unique_id()")
         self._check(self._lib.ba_comm_init(self._h, rank, world, unique_id))
+
+    def table_digests(self) -> list:
+        """Digests of the tables of the last set_problem (ba_debug_table_digests; needs BA_TABLE_DIGEST=1 in the environment)."""
+        n = C.c_int32()
+        self._check(self._lib.ba_debug_table_digests(self._h, None, 0, C.byref(n)))
+        buf = (C.c_uint64 * max(1, n.value))()
+        self._check(self._lib.ba_debug_table_digests(self._h, buf, n.value, C.byref(n)))
+        return [int(v) for v in buf[: n.value]]
 
     def comm_info(self):
         """(rank, world) as the communicator itself reports them (ba_comm_info); (0, 1) without one."""
