@@ -38,7 +38,7 @@ WORKLOADS = {  # name -> (cameras, landmarks, track length)       (SURVEY.md sec
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 STREAMING = ("k_linearize", "k_schur", "k_gather_S", "k_backsub", "k_cost")
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def algorithmic_bytes(kernel: str, nobs: int, n_lm: int, n_cam: int, info: dict) -> float:
@@ -95,6 +95,66 @@ def cpu_baseline(scene, budget_s: float):
         "seconds": wall, "cost": float(res.cost), "nfev": int(res.nfev), "status": int(res.status),
         "host_cpus": os.cpu_count(),
     }
+
+
+GOLDEN = {"cfg2": "ring_50x20000.npz", "cfg3": "ring_1000x200000.npz"}
+
+
+def like_for_like(name: str, scene, rep, device: int, optimize_wall: bool) -> dict:
+    """What a caller of the reference's entry point compares (untimed for `value`; single GPU):
+    * time_to_reference_cost_ms: the solve cut off at the first LM iteration whose cost is at or below the cost the
+      reference's own least_squares call reached on this scene (tests/golden/<scene>.npz `ref_cost`, written by
+      oracle/make_golden.py with the reference's residual_function and settings) -- the like-for-like time-to-converge;
+    * reference_tolerances: a solve with the reference's ftol = xtol = gtol = 1e-6 (bundle_adjustment.py:207-209)
+      instead of this library's tighter defaults;
+    * optimize_wall_ms (configs[1] only): BundleAdjustment.optimize on the reference's containers, end to end: packing,
+      ba_create, ba_set_problem, ba_solve, unpacking and the re-projection of bundle_adjustment.py:246-286."""
+    import scenes
+    from src import _native
+    out = {}
+    C, L = len(scene["poses_guess"]), len(scene["points_guess"])
+
+    def timed_solve(reps, **opts):
+        best, last = None, None
+        with _native.Solver(device=device, **opts) as s:
+            s.set_problem(C, L, scene["obs_cam"], scene["obs_pt"], scene["obs_uv"], scene["intr"])
+            s.upload_guess(scene["poses_guess"], scene["points_guess"])
+            for _ in range(reps):
+                last = s.solve_resident()
+                best = last["solve_ms"] if best is None else min(best, last["solve_ms"])
+        return best, last
+
+    path = os.path.join(ROOT, "tests", "golden", GOLDEN.get(name, ""))
+    if name in GOLDEN and os.path.exists(path):
+        ref_cost = float(np.load(path)["ref_cost"])
+        hist = rep["cost_history"]
+        hit = next((i for i, c in enumerate(hist) if c <= ref_cost), None)
+        if hit is not None:
+            ms, cut = timed_solve(3, max_iters=hit + 1)
+            out["time_to_reference_cost_ms"] = ms
+            out["time_to_reference_cost"] = {"reference_cost": ref_cost, "lm_iterations": hit + 1, "cost_there": cut["cost"],
+                                             "ms": ms, "note": "best of 3 solves cut off at that iteration; the reference's "
+                                             "cost is the one its own least_squares call reaches on this scene "
+                                             f"(tests/golden/{GOLDEN[name]})"}
+    ms, r = timed_solve(3, ftol=1e-6, xtol=1e-6, gtol=1e-6)
+    out["reference_tolerances"] = {"ftol": 1e-6, "xtol": 1e-6, "gtol": 1e-6, "time_to_converge_ms": ms,
+                                   "lm_iterations": r["iterations"], "final_cost": r["cost"], "status": r["status_name"]}
+    if optimize_wall:
+        from src.bundle_adjustment import BundleAdjustment
+        args = scenes.to_containers(scene)
+        walls, ba = [], BundleAdjustment(device=device)
+        for _ in range(4):
+            t0 = time.perf_counter()
+            ba.optimize(*args)
+            walls.append(1e3 * (time.perf_counter() - t0))
+        lr = ba.last_report
+        out["optimize_wall_ms"] = min(walls[1:])
+        out["optimize_wall"] = {"ms": min(walls[1:]), "first_call_ms": walls[0], "setup_ms": lr["setup_ms"],
+                                "solve_ms": lr["solve_ms"], "final_cost": lr["cost"],
+                                "note": "BundleAdjustment.optimize(image_features_list, pose0, camera, poses_guess, points3d_guess), "
+                                        "best of 3 after one warm-up call; setup_ms / solve_ms are the library's own share "
+                                        "(ba_set_problem / ba_solve), the rest is Python packing, unpacking and re-projection"}
+    return out
 
 
 def pmc_traffic(workload: str) -> dict:
@@ -297,6 +357,8 @@ def main():
     ap.add_argument("--lm-check-every", type=int, default=None, help="override ba_options.lm_check_every")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--max-iters", type=int, default=None, help="cap the LM iterations of a solve (profiling passes only)")
+    ap.add_argument("--no-like-for-like", action="store_true",
+                    help="skip the legs behind time_to_reference_cost_ms / reference_tolerances / optimize_wall_ms")
     ap.add_argument("--control-plane-only", action="store_true",
                     help="rehearsal of the launch path without a GPU: ranks rendezvous (gloo), report themselves and exit")
     args = ap.parse_args()
@@ -349,14 +411,19 @@ def main():
                "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True, "scaling": args.scaling,
                "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
         out.update(res)
+        if world == 1 and not args.no_like_for_like:
+            out.update(like_for_like(args.workload, scene, rep, int(os.environ.get("BA_BENCH_DEVICE", local_rank)),
+                                     optimize_wall=args.workload in ("cfg2", "small")))
         if world == 1 and args.large != "none":
             # the configurations that leave the Infinity Cache: a short leg each, same protocol
             for name in args.large.split(","):
                 if name == args.workload or name not in WORKLOADS:
                     continue
                 steps = 3 if name == "cfg3" else 1
-                leg, _, _ = run_workload(args, name, steps, 1 if name == "cfg3" else 0, None, 0, 1, local_rank,
-                                         kernel_events=not args.no_kernel_events, solver_opts=cap)
+                leg, leg_scene, leg_rep = run_workload(args, name, steps, 1 if name == "cfg3" else 0, None, 0, 1, local_rank,
+                                                       kernel_events=not args.no_kernel_events, solver_opts=cap)
+                if name == "cfg3" and not args.no_like_for_like:
+                    leg.update(like_for_like(name, leg_scene, leg_rep, int(os.environ.get("BA_BENCH_DEVICE", local_rank)), False))
                 leg["steps"] = steps
                 leg.pop("n_gpus", None)
                 leg["unit"] = "observations*iterations/s"

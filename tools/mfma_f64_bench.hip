@@ -30,18 +30,18 @@ __global__ __launch_bounds__(256) void kf(double* out, int iters) {
 }
 int main() {
   double* d; (void)hipMalloc(&d, 256 * 1024 * 8 * 8);
-  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int blocks : {1, 256, 1024}) {
     int iters = 4096;
     k<<<blocks, 256>>>(d, 16);
-    hipEventRecord(e0); k<<<blocks, 256>>>(d, iters); hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventRecord(e0); k<<<blocks, 256>>>(d, iters); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     double mf = (double)iters * 8;  // mfma per wave
     printf("mfma f64 16x16x4: blocks %d: %.3f ms, %.1f ns per MFMA per wave, %.2f TFLOP/s\n", blocks, ms, ms * 1e6 / mf,
            blocks * 4.0 * mf * 2048 / (ms * 1e-3) / 1e12);
     kf<<<blocks, 256>>>(d, 16);
-    hipEventRecord(e0); kf<<<blocks, 256>>>(d, iters); hipEventRecord(e1); hipEventSynchronize(e1);
-    hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventRecord(e0); kf<<<blocks, 256>>>(d, iters); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
     printf("v_fma_f64: blocks %d: %.3f ms, %.2f ns per FMA per wave, %.2f TFLOP/s\n", blocks, ms, ms * 1e6 / (iters * 16.0),
            blocks * 4.0 * iters * 16.0 * 128 / (ms * 1e-3) / 1e12);
   }

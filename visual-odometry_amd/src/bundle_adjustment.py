@@ -36,23 +36,32 @@ def _pack_observations(observations: List[ImageFeatures], landmark_ids: np.ndarr
     sorted_ids = landmark_ids[order]
     if len(sorted_ids) > 1 and np.any(sorted_ids[1:] == sorted_ids[:-1]):
         raise ValidationError("landmark ids must be unique")
-    cams, pts, uvs = [], [], []
-    for i, feats in enumerate(observations):
-        f2d = feats.get_points_2d()
-        ids = f2d.get_ids()
-        if len(ids) == 0:
-            continue
-        pos = np.searchsorted(sorted_ids, ids)
-        pos = np.clip(pos, 0, len(sorted_ids) - 1)
-        if np.any(sorted_ids[pos] != ids):
-            missing = ids[sorted_ids[pos] != ids][0]
-            raise ValidationError(f"image {i} observes landmark id {missing} that is not in points3d_guess")
-        cams.append(np.full(len(ids), i, dtype=np.int32))
-        pts.append(order[pos].astype(np.int32))
-        uvs.append(f2d.get_points_2d())
-    if not cams:
+    id_sets = [feats.get_points_2d().get_ids() for feats in observations]
+    counts = np.array([len(ids) for ids in id_sets])
+    if counts.sum() == 0:
         raise ValidationError("no observations")
-    return np.concatenate(cams), np.concatenate(pts), np.vstack(uvs)
+    all_ids = np.concatenate(id_sets)
+    # id -> index in landmark_ids: a direct table when the ids are small non-negative integers (the usual case: one
+    # gather instead of a binary search per observation), else a search in the sorted ids
+    table = None
+    if np.issubdtype(landmark_ids.dtype, np.integer) and np.issubdtype(all_ids.dtype, np.integer) and len(sorted_ids) > 0 \
+            and sorted_ids[0] >= 0 and sorted_ids[-1] < 4 * len(sorted_ids) + 1024:
+        table = np.full(int(sorted_ids[-1]) + 1, -1, dtype=np.int64)
+        table[landmark_ids] = np.arange(len(landmark_ids))
+        inside = (all_ids >= 0) & (all_ids < len(table))
+        index = np.where(inside, table[np.where(inside, all_ids, 0)], -1)
+        bad = index < 0
+    else:
+        pos = np.clip(np.searchsorted(sorted_ids, all_ids), 0, len(sorted_ids) - 1)
+        bad = sorted_ids[pos] != all_ids
+        index = order[pos]
+    if np.any(bad):
+        k = int(np.argmax(bad))
+        image = int(np.searchsorted(np.cumsum(counts), k, side="right"))
+        raise ValidationError(f"image {image} observes landmark id {all_ids[k]} that is not in points3d_guess")
+    cams = np.repeat(np.arange(len(observations), dtype=np.int32), counts)
+    uvs = np.vstack([feats.get_points_2d().get_points_2d() for feats, c in zip(observations, counts) if c > 0])
+    return cams, index.astype(np.int32), uvs
 
 
 def _pose_rows(camera_pose_initial: CameraPose, poses: List[CameraPose]) -> np.ndarray:
@@ -160,13 +169,14 @@ class BundleAdjustment:
         optimized_points3d = Landmarks3D(points, landmark_ids)
 
         # re-project the observed landmarks through the optimised poses (reference :246-286);
-        # width/height come from image 0 (:190-191)
+        # width/height come from image 0 (:190-191).  The packed observations are image-major: image i owns one slice.
         image_width = image_features_list[0].image_width
         image_height = image_features_list[0].image_height
+        starts = np.searchsorted(obs_cam, np.arange(n_cams + 1))
         optimized_image_features = []
         for i, feats in enumerate(image_features_list):
-            sel = obs_cam == i
-            if not np.any(sel):
+            sel = slice(starts[i], starts[i + 1])
+            if starts[i] == starts[i + 1]:
                 optimized_image_features.append(feats)
                 continue
             pts_cam = optimized_camera_poses[i].transform_points_world_to_camera(points[obs_pt[sel]])
