@@ -45,10 +45,13 @@ def algorithmic_bytes(kernel: str, nobs: int, n_lm: int, n_cam: int, info: dict)
     """Bytes one launch must move (DESIGN.md 'Kernels').  W travels factored (12 doubles = 96 B per observation instead
     of SURVEY.md section 8d's 144 B: csrc/ba_kernels.h, w_from_j), so these figures are below the survey's."""
     mf = info.get("linearize_flat", 0) & 4  # matrix-free path (>= 2 M observations): W is rebuilt, never stored
+    # round 3 (k_linearize_rows): U | gc leave the linearisation as one row of 27 doubles per (chunk, camera) instead of
+    # atomics into slabs; the fold blocks at the end of the Schur launch read them and write the slabs the gather sums
+    rows = 216.0 * info.get("u_rows", 0)
     if kernel == "k_linearize":  # read cam idx + u + v, write the factors of W; per landmark read P, write V + gp; U/gc per camera
-        return (24.0 if mf else 120.0) * nobs + 120.0 * n_lm + 392.0 * n_cam
+        return (24.0 if mf else 120.0) * nobs + 120.0 * n_lm + (rows if rows else 392.0 * n_cam)
     if kernel == "k_schur":  # read the factors of W + cam idx (mf: the record, 28 B); per landmark V + gp (mf: + P); S written once
-        return (28.0 * nobs + 120.0 * n_lm) if mf else (100.0 * nobs + 96.0 * n_lm)
+        return ((28.0 * nobs + 120.0 * n_lm) if mf else (100.0 * nobs + 96.0 * n_lm)) + rows + (216.0 * n_cam * info["u_slabs"] if rows else 0.0)
     if kernel == "k_backsub":  # read the factors of W + cam idx; per landmark V, gp, P read, P written
         if mf:
             return 28.0 * nobs + 152.0 * n_lm
@@ -73,9 +76,10 @@ def iteration_bytes(nobs: int, n_lm: int, n_cam: int, info: dict = None) -> floa
     """Algorithmic bytes of one accepted LM iteration (before the reduced solve): SURVEY.md section 8(d)'s 480 B per
     observation less 3 x 48 B (W written once and read twice, factored: 96 B instead of 144 B); on the matrix-free path
     the observation records only (24 + 28 + 28 B)."""
+    rows = 2 * 216.0 * info.get("u_rows", 0) if info else 0.0  # the U | gc rows, written once and read once (round 3)
     if info and info.get("linearize_flat", 0) & 4:
-        return 80.0 * nobs + 432.0 * n_lm + 900.0 * n_cam
-    return 336.0 * nobs + 384.0 * n_lm + 900.0 * n_cam
+        return 80.0 * nobs + 432.0 * n_lm + 900.0 * n_cam + rows
+    return 336.0 * nobs + 384.0 * n_lm + 900.0 * n_cam + rows
 
 
 def cpu_baseline(scene, budget_s: float):

@@ -31,9 +31,10 @@
 extern "C" {
 #endif
 
-#define BA_AMD_VERSION 101 /* 0.1.1: ba_report gained bad_pivots / guard_rejections / shortened_steps, BA_KERNEL_CLASSES
-                              went from 6 to 8 (ba_get_kernel_times writes 8 entries), ba_comm_info is new: a caller built
-                              against version 100 must be rebuilt (compare ba_version() with the header it was built with) */
+#define BA_AMD_VERSION 102 /* 0.1.2: ba_problem_info writes 13 entries (BA_INFO_COUNT was 12), ba_debug_table_digests is new.
+                              0.1.1: ba_report gained bad_pivots / guard_rejections / shortened_steps, BA_KERNEL_CLASSES
+                              went from 6 to 8 (ba_get_kernel_times writes 8 entries), ba_comm_info is new.  A caller built
+                              against an older version must be rebuilt (compare ba_version() with the header it was built with) */
 #define BA_HISTORY 128     /* per-iteration history entries kept in ba_report: the first BA_HISTORY - 1 iterations and,
                               in the last entry, the most recent one (a solve may run longer; n_history stops at 128) */
 
@@ -328,9 +329,11 @@ int ba_reduced_solver(const ba_handle* h, int32_t* kind);
  * ba_reduced_solver), 5 / 6 half-bandwidth and arrow size of the banded solver (level 2 when segmented; cyclic reduction:
  * cameras per super-block and levels), 7 segments of the two-level banded solver (0: one level; cyclic reduction:
  * super-blocks), 8 free cameras, 9 observed landmarks, 10 kernel choices as bits (1: k_linearize_flat, 2: k_backsub_flat,
- * 4: matrix-free path: no stored W, the Schur and back-substitution kernels rebuild it; 8: k_linearize_win),
- * 11 connected components of the camera graph. */
-#define BA_INFO_COUNT 12
+ * 4: matrix-free path: no stored W, the Schur and back-substitution kernels rebuild it; 8: k_linearize_win;
+ * 16: k_linearize_rows, the fixed-order linearisation of round 3), 11 connected components of the camera graph,
+ * 12 rows of 27 doubles (U | gc of one camera within one chunk) that k_linearize_rows writes and the fold blocks of the
+ * Schur launch read per linearisation (0 on the other paths). */
+#define BA_INFO_COUNT 13
 int ba_problem_info(const ba_handle* h, int64_t* info);
 
 /* Number of stored 6x6 blocks of the reduced camera system (upper triangle incl. diagonal). */

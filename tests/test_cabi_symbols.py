@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/ba_amd.h but not exported"
     assert set(names) == set(_native.EXPORTED_SYMBOLS)
-    assert lib.ba_version() == 101
+    assert lib.ba_version() == 102
 
 
 def test_struct_layouts_match_header():

@@ -127,6 +127,24 @@ def test_lm_oracle_reaches_polished_minimum(golden, name):
     assert rep.cost <= float(g["ref_cost"]) * (1 + 1e-6)
 
 
+@pytest.mark.parametrize("seed", [0, 333, 700, 1023])
+def test_lm_oracle_reaches_polished_minimum_of_the_reference_run_windows(golden, seed):
+    """The chain behind the full-size two-sided bars: on the four config-5 windows that went through
+    the reference's own BundleAdjustment.optimize (tests/golden/window_<seed>_10x100.npz, oracle/make_golden.py), the
+    numpy LM must land on the minimum that scipy's dense exact trust region finds from the reference's result (an
+    independent code path), and at or below the reference's own cost."""
+    g = golden(f"window_{seed}_10x100")
+    _, _, rep = lm.lm_solve(g["poses_guess"], g["points_guess"], g["obs_cam"], g["obs_pt"], g["obs_uv"], g["intr"])
+    pol, ref = float(g["polished_cost"]), float(g["ref_cost"])
+    assert str(g["polished_by"]).startswith("scipy trf exact")
+    assert abs(rep.cost - pol) <= 1e-6 * pol, (rep.cost, pol)
+    assert rep.cost <= ref * (1 + 1e-6)
+    # the reference's residual_function at the guess is what the restated residual gives (1e-9 px)
+    x0 = np.concatenate([g["poses_guess"][1:].reshape(-1), g["points_guess"].reshape(-1)])
+    r = orc.residual_packed(x0, g["poses_guess"][0], len(g["poses_guess"]) - 1, g["obs_cam"], g["obs_pt"], g["obs_uv"], g["intr"])
+    np.testing.assert_allclose(r, g["residual_at_x0"], rtol=0, atol=1e-9)
+
+
 def test_distorted_jacobian_vs_finite_differences(golden):
     """Blocks of the LM oracle with radial distortion (src/camera.py:141-159) against central differences
     of the reference-path residual."""

@@ -1185,8 +1185,8 @@ int ba_problem_info(const ba_handle* h, int64_t* info) {
                                     h->bcr_solve ? h->bcr_plan.m / 6 : h->banded_solve ? h->bshape.bw : 0,
                                     h->bcr_solve ? h->bcr_plan.n_levels : h->banded_solve ? h->bshape.na : 0,
                                     h->bcr_solve ? h->bcr_plan.N : h->bseg_P,
-                                    h->Cf, h->L_obs, (h->lin_cpw > 0 ? 1 : 0) | (h->flat_chunks > 0 && h->use_flat_backsub ? 2 : 0) | (h->matrix_free ? 4 : 0) | (h->lin_win ? 8 : 0),
-                                    h->d.n_comp};
+                                    h->Cf, h->L_obs, (h->lin_cpw > 0 ? 1 : 0) | (h->flat_chunks > 0 && h->use_flat_backsub ? 2 : 0) | (h->matrix_free ? 4 : 0) | (h->lin_win ? 8 : 0) | (h->lin_rows ? 16 : 0),
+                                    h->d.n_comp, (int64_t)h->d.n_urows};
   for (int i = 0; i < BA_INFO_COUNT; ++i) info[i] = v[i];
   return BA_OK;
 }

@@ -393,10 +393,10 @@ class Solver:
         return self.REDUCED_SOLVERS[v.value]
 
     INFO_KEYS = ("s_blocks", "contrib_rows", "schur_chunks", "u_slabs", "reduced_solver", "band_bw", "band_arrow",
-                 "band_segments", "free_cameras", "observed_landmarks", "linearize_flat", "components")
+                 "band_segments", "free_cameras", "observed_landmarks", "linearize_flat", "components", "u_rows")
 
     def problem_info(self) -> dict:
-        v = (C.c_int64 * 12)()
+        v = (C.c_int64 * len(self.INFO_KEYS))()
         self._check(self._lib.ba_problem_info(self._h, v))
         return {k: int(v[i]) for i, k in enumerate(self.INFO_KEYS)}
 
