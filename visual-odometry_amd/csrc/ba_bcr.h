@@ -1052,9 +1052,116 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_tail(double* __restrict__ B
   const int done = ctrl ? ctrl->done : 0;  // looked at after the round of loads (see k_bcr_factor)
   const int mm = m * m, n = lv.n, Nd = n * m, ld = Nd + 1, nb = Nd / 6, R = Nd + 1;
   const int tid = threadIdx.x;
-  double* T = lds;                      // [R][ld]
+  // Two blocks of 24 rows (the tail of a trajectory with tracks of five): eliminate block 0 with the four-wave register
+  // factorisation of the levels (bcr_factor_T: [D_0; C; .; I; r_0] -> [L_0; F = C L_0^-T; .; L_0^-T; y_0]), form
+  // D_1 - F F^T on one wave and r_1 - F y_0 on another, factor that the same way, and substitute back with four
+  // mat-vecs of 24: 8 us where the 48-row factorisation on ONE wave took 14 (wall_clock64).
+  const bool two_blocked = n == 2 && m == 24;
+  const int ldb = m + 1, Rb = 4 * m + 1;
+  double* T = lds;                      // [R][ld]   (two_blocked: T1 [Rb][ldb] | T2 [Rb][ldb] | P2 [m][ldb])
   double* sLi = T + (long)R * ld;       // [nb][36] inverses of the diagonal blocks of L
-  double* xs = sLi + nb * 36;           // [Nd]
+  double* xs = two_blocked ? lds + 2L * Rb * ldb + (long)m * ldb : sLi + nb * 36;  // [Nd]
+  if (two_blocked) {
+    double* T1 = lds;
+    double* T2 = T1 + (long)Rb * ldb;
+    double* P2 = T2 + (long)Rb * ldb;
+    double* bcast = bcr_align16(lds, xs + Nd);
+    double d0[BCR_EPT], d1[BCR_EPT], e0[BCR_EPT], e1[BCR_EPT];
+#pragma unroll
+    for (int u = 0; u < BCR_EPT; ++u) {
+      const int w = tid + u * BCR_THREADS;
+      d0[u] = d1[u] = e0[u] = e1[u] = 0.0;
+      if (w < mm) {
+        const int r = w / m, c = w - r * m;
+        d0[u] = B[lv.D + w]; d1[u] = B[lv.D + mm + w];
+        e0[u] = B[lv.E + c * m + r];  // E_0^T: block (1, 0)
+        e1[u] = B[lv.E + mm + w];     // E_1 = block (1, 0) as it is (the loop closure)
+      }
+    }
+    const double rv = tid < Nd ? B[lv.r + tid] : 0.0;
+    if (done) return;
+#pragma unroll
+    for (int u = 0; u < BCR_EPT; ++u) {
+      const int w = tid + u * BCR_THREADS;
+      if (w < mm) {
+        const int r = w / m, c = w - r * m;
+        const double id = r == c ? 1.0 : 0.0;
+        T1[r * ldb + c] = d0[u]; T1[(m + r) * ldb + c] = e0[u] + e1[u]; T1[(2 * m + r) * ldb + c] = 0.0; T1[(3 * m + r) * ldb + c] = id;
+        T2[r * ldb + c] = d1[u]; T2[(m + r) * ldb + c] = 0.0; T2[(2 * m + r) * ldb + c] = 0.0; T2[(3 * m + r) * ldb + c] = id;
+      }
+    }
+    if (tid < m) T1[4 * m * ldb + tid] = rv;
+    else if (tid < Nd) T2[4 * m * ldb + tid - m] = rv;
+    __syncthreads();
+    BCR_CUT(1);  // assembly in LDS
+    if (top.n > 0 && tid >= 192) {
+      // (the factors of the folded back-substitution levels were written on other XCDs: one word of each 128-byte line
+      // requested now, by a wave whose share of the factorisation is the smallest, so that they are close when needed)
+      double sink = 0.0;
+      for (int t = 0; t < top.n; ++t) {
+        const long words = (long)top.lv[t].n_elim * mm;
+        for (long e = (long)(tid - 192) * 16; e < words; e += 64 * 16)
+          sink += B[top.lv[t].Fa + e] + B[top.lv[t].Fb + e] + B[top.lv[t].LiT + e];
+      }
+      if (sink == 1.2345678e-300) xs[0] = sink;  // (never true; keeps the loads)
+    }
+    bool bad = bcr_factor_T(T1, m, ldb, tid, bcast);
+    const double* F = T1 + (long)m * ldb;
+    if (tid < 64) {
+      double acc[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) acc[q] = 0.0;
+      bcr_gemm24_xyt(F, F, tid, acc);
+      const int r0 = 3 * (tid >> 3), c0 = 3 * (tid & 7);
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) P2[(r0 + a) * ldb + c0 + b2] = acc[3 * a + b2];
+    } else if (tid < 64 + m) {
+      const int r = tid - 64;
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int t = 0; t < 24; t += 2) {
+        s0 = fma(F[r * ldb + t], T1[4 * m * ldb + t], s0);
+        s1 = fma(F[r * ldb + t + 1], T1[4 * m * ldb + t + 1], s1);
+      }
+      T2[4 * m * ldb + r] -= s0 + s1;
+    }
+    __syncthreads();
+    if (bcr_factor_T(T2, m, ldb, tid, bcast, P2)) bad = true;
+    double* tb = P2;  // (free again)
+    if (tid < m) {  // x_1 = L_1^-T y_1
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 24; k += 2) {
+        s0 = fma(T2[(3 * m + tid) * ldb + k], T2[4 * m * ldb + k], s0);
+        s1 = fma(T2[(3 * m + tid) * ldb + k + 1], T2[4 * m * ldb + k + 1], s1);
+      }
+      xs[m + tid] = s0 + s1;
+    }
+    __syncthreads();
+    if (tid < m) {  // t = y_0 - F^T x_1
+      double s0 = T1[4 * m * ldb + tid], s1 = 0.0;
+#pragma unroll
+      for (int r = 0; r < 24; r += 2) {
+        s0 = fma(-F[r * ldb + tid], xs[m + r], s0);
+        s1 = fma(-F[(r + 1) * ldb + tid], xs[m + r + 1], s1);
+      }
+      tb[tid] = s0 + s1;
+    }
+    __syncthreads();
+    if (tid < m) {  // x_0 = L_0^-T t
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 24; k += 2) {
+        s0 = fma(T1[(3 * m + tid) * ldb + k], tb[k], s0);
+        s1 = fma(T1[(3 * m + tid) * ldb + k + 1], tb[k + 1], s1);
+      }
+      xs[tid] = s0 + s1;
+    }
+    __syncthreads();
+    if (bad && tid == 0) atomic_add_f64(badv, 1.0);
+  } else {
   const bool two_in_regs = n == 2 && (Nd == 48 || Nd == 60);  // the usual tail: two blocks, solved out of registers
   if (two_in_regs) {
     // [D_0 . ; E_0^T + E_1  D_1 | r]: every entry of the lower triangle has one writer, everything is requested in ONE
@@ -1203,6 +1310,8 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_tail(double* __restrict__ B
       __syncthreads();
     }
   }
+  if (bad && tid == 0) atomic_add_f64(badv, 1.0);
+  }  // !two_blocked
   BCR_CUT(2);  // factor + sweep
   double* __restrict__ X = B + Xoff;
   double* xtop = bcr_align16(lds, xs + Nd) + BCR_BCAST;  // [top.nx][m]: x of the blocks of the folded levels
@@ -1213,7 +1322,6 @@ __global__ __launch_bounds__(BCR_THREADS) void k_bcr_tail(double* __restrict__ B
     if (top.n > 0) xtop[(o >> top.xshift) * m + c] = xs[e];
     if (c < 6 * cnt[o]) dc[6L * cam0[o] + c] = xs[e];
   }
-  if (bad && tid == 0) atomic_add_f64(badv, 1.0);
   for (int t = 0; t < top.n; ++t) {  // the top back-substitution levels, highest first: a wave per eliminated block
     __syncthreads();                  // x of the level above is in xtop
     for (int q = tid >> 6; q < top.lv[t].n_elim; q += BCR_THREADS / 64)

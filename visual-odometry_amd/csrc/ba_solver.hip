@@ -2203,6 +2203,8 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
             h->bcr_top = top;
             const size_t nd = (size_t)pl.lv[pl.n_levels].n * m;
             h->bcr_lds_tail = ((nd + 1) * (nd + 1) + (nd / 6) * 36 + nd + BCR_BCAST + 2 + (size_t)top.nx * m) * sizeof(double);
+            if (pl.lv[pl.n_levels].n == 2 && m == 24)  // the blocked tail: T1 | T2 | P2 | x | broadcast buffers | x of the folded levels
+              h->bcr_lds_tail = ((size_t)(2 * (4 * m + 1) + m) * (m + 1) + nd + BCR_BCAST + 2 + (size_t)top.nx * m) * sizeof(double);
             HIP_TRY(h, hipFuncSetAttribute((const void*)k_bcr_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bcr_lds_tail));
           }
           h->banded_solve = false; h->bseg_P = 0; h->dense_solve = false; h->small_solve = false;
