@@ -299,6 +299,10 @@ int ba_set_kernel_timing(ba_handle* h, int32_t on);
  * bit-identical PROVIDED the all-reduce hands every rank the same bits (true of RCCL's ring and tree algorithms, where
  * every rank receives the one reduced buffer; checked with the test stand-in for librccl, not yet on a multi-GPU node).
  * Only the multi-kernel PCG, which reduces with atomics, ships rank 0's step.
+ * BA_SHARDED_SOLVE=1 in the environment of EVERY rank (opt-in) shards the reduced solve of a trajectory by camera segment
+ * instead: partial S per rank, one ncclReduce per rank of its segments of the two-level banded solver, local elimination
+ * of the segment interiors, an all-reduce of the separator system, a replicated separator solve, local back-substitution,
+ * an all-reduce of the camera step (one writer per entry: bit-identical poses); ba_problem_info[10] & 32 reports it.
  * Every rank needs at least one landmark and one observation.  ba_set_problem, ba_upload_guess and ba_solve* agree on
  * a status before their first data collective: if any rank's arguments are bad (an empty shard, an index out of range,
  * a non-finite guess) EVERY rank returns that status and none is left waiting inside RCCL.  ba_evaluate /
@@ -330,7 +334,8 @@ int ba_reduced_solver(const ba_handle* h, int32_t* kind);
  * cameras per super-block and levels), 7 segments of the two-level banded solver (0: one level; cyclic reduction:
  * super-blocks), 8 free cameras, 9 observed landmarks, 10 kernel choices as bits (1: k_linearize_flat, 2: k_backsub_flat,
  * 4: matrix-free path: no stored W, the Schur and back-substitution kernels rebuild it; 8: k_linearize_win;
- * 16: k_linearize_rows, the fixed-order linearisation of round 3), 11 connected components of the camera graph,
+ * 16: k_linearize_rows, the fixed-order linearisation of round 3; 32: reduced solve sharded by camera segment, see the
+ * multi-GPU notes), 11 connected components of the camera graph,
  * 12 rows of 27 doubles (U | gc of one camera within one chunk) that k_linearize_rows writes and the fold blocks of the
  * Schur launch read per linearisation (0 on the other paths). */
 #define BA_INFO_COUNT 13

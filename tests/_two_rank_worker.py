@@ -74,9 +74,11 @@ def main():
         s.set_problem(C, len(sh["points"]), sh["obs_cam"], sh["obs_pt"], sh["obs_uv"], sc["intr"])
         P, X, rep = s.solve(sc["poses_guess"], sh["points"])
         kind = s.reduced_solver()
+        info = s.problem_info()
     np.savez(os.path.join(workdir, f"rank{rank}.npz"), poses=P, points=X, lo=sh["lm_lo"], hi=sh["lm_hi"],
              cost=rep["cost"], cost0=rep["cost0"], iterations=rep["iterations"], status=rep["status"],
-             nobs=rep["nobs"], solver=kind)
+             nobs=rep["nobs"], solver=kind, sharded_solve=(info["linearize_flat"] >> 5) & 1, segments=info["band_segments"],
+             bad_pivots=rep["bad_pivots"])
 
 
 if __name__ == "__main__":

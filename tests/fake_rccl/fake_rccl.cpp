@@ -150,6 +150,26 @@ ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataT
   return ncclSuccess;
 }
 
+// (sum to one rank; the other ranks' receive buffers are left alone, as RCCL leaves them)
+ncclResult_t ncclReduce(const void* send, void* recv, size_t count, ncclDataType_t type, ncclRedOp_t op, int root,
+                        ncclComm_t c, hipStream_t stream) {
+  if (type != ncclDouble || op != ncclSum) die("reduce flavour not handled by the shim");
+  const size_t bytes = count * sizeof(double);
+  publish(c, send, bytes, stream);
+  if (c->rank == root) {
+    double* acc = static_cast<double*>(std::malloc(bytes ? bytes : 8));
+    std::memcpy(acc, c->slots, bytes);
+    for (int r = 1; r < c->world; ++r) {
+      const double* x = reinterpret_cast<const double*>(c->slots + (size_t)r * SLOT_BYTES);
+      for (size_t i = 0; i < count; ++i) acc[i] += x[i];
+    }
+    if (hipMemcpy(recv, acc, bytes, hipMemcpyHostToDevice) != hipSuccess) die("host-to-device copy failed");
+    std::free(acc);
+  }
+  barrier(c);  // nobody overwrites a slot before the root has read it
+  return ncclSuccess;
+}
+
 ncclResult_t ncclBroadcast(const void* send, void* recv, size_t count, ncclDataType_t type, int root, ncclComm_t c,
                            hipStream_t stream) {
   const size_t bytes = count * type_bytes(type);

@@ -135,3 +135,21 @@ def test_sharded_solve_with_several_iterations_per_host_poll(tmp_path):
     P0, X0, rep0 = single_gpu(sc, ftol=1e-12)
     parts = run_ranks(2, "ring_long", tmp_path, ftol=1e-12, lm_check_every=3)
     check_against_single(parts, sc, P0, X0, rep0, atol=1e-6)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_reduced_solve_sharded_by_camera_segment(world, tmp_path, monkeypatch):
+    """BA_SHARDED_SOLVE=1 (opt-in): the reduced camera system of a trajectory is not solved on every
+    rank.  S is scattered per rank as a partial sum, the camera segments of the two-level banded solver travel to their
+    owners by one reduce per rank, every rank eliminates the interiors of its own segments, the separator system is
+    all-reduced and solved on every rank, the ranks back-substitute their own segments, and the camera step is summed
+    (one writer per entry).  Against the single-GPU solve (cyclic reduction there): cost 1e-8, estimates 1e-6; the
+    replicated poses bit-identical on all ranks."""
+    monkeypatch.setenv("BA_SHARDED_SOLVE", "1")
+    sc = scenes.ring_scene(300, 3000, 6)
+    P0, X0, rep0 = single_gpu(sc, ftol=1e-12)
+    parts = run_ranks(world, "ring_long", tmp_path, ftol=1e-12)
+    for part in parts:
+        assert str(part["solver"]) == "banded_cholesky" and int(part["sharded_solve"]) == 1, (str(part["solver"]), int(part["sharded_solve"]))
+        assert int(part["segments"]) % world == 0 and int(part["bad_pivots"]) == 0
+    check_against_single(parts, sc, P0, X0, rep0, atol=1e-6)

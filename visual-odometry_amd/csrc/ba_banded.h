@@ -316,7 +316,8 @@ struct BandedSeg {
 // transposed, rdst[f] = offset of the rhs row of free camera f.  B must be zero.
 __global__ __launch_bounds__(256) void k_bseg_assemble(DeviceProblem d, double* __restrict__ B, const long* __restrict__ dst,
                                                        const unsigned char* __restrict__ tr, const long* __restrict__ rdst,
-                                                       double lam, double min_diag, int solver_mode) {
+                                                       double lam, double min_diag, int solver_mode,
+                                                       const int* __restrict__ cam_owner = nullptr, int rank = 0) {
   if (solver_mode) {
     if (d.ctrl->done) return;
     lam = d.ctrl->lam;
@@ -330,7 +331,8 @@ __global__ __launch_bounds__(256) void k_bseg_assemble(DeviceProblem d, double* 
     double* blk = B + dst[s];
     if (i == j) {
       if (c > r) return;
-      if (r == c) v += lam * fmax(u_diag(d, i, r), min_diag);
+      // (sharded solve: d.S is this rank's partial sum; the damping comes from the camera's owner alone)
+      if (r == c && (cam_owner == nullptr || cam_owner[i] == rank)) v += lam * fmax(u_diag(d, i, r), min_diag);
       blk[6 * r + c] = v;
       blk[6 * c + r] = v;
     } else if (tr[s]) {
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256) void k_bseg_assemble(DeviceProblem d, double* 
   } else if (t < nS + 6L * d.Cf) {
     const long p = t - nS;
     const int k = (int)(p / 6), e = (int)(p - 6L * k);
-    B[rdst[k] + e] = -d.rhs[p];
+    if (cam_owner == nullptr || cam_owner[k] == rank) B[rdst[k] + e] = -d.rhs[p];  // (sharded: rhs is all-reduced, one writer)
   }
 }
 
@@ -461,9 +463,11 @@ __global__ __launch_bounds__(BND_THREADS) void k_bseg_factor(double* __restrict_
 __global__ __launch_bounds__(256) void k_bseg_corner_add(double* __restrict__ Ball, const BandedSeg* __restrict__ segs, int bw,
                                                          int parity, const long* __restrict__ cdst,
                                                          const unsigned char* __restrict__ ctr, const long* __restrict__ crdst,
-                                                         const LmCtrl* ctrl) {
+                                                         const LmCtrl* ctrl, int b0, int b1) {
   if (ctrl && ctrl->done) return;
-  const int b = 2 * blockIdx.x + parity;
+  // segments [b0, b1) (all of them on one GPU; a rank's own in the sharded solve), those of this parity
+  const int b = b0 + ((parity - b0) & 1) + 2 * blockIdx.x;
+  if (b >= b1) return;
   const BandedSeg sg = segs[b];
   const int na = 2 * bw, nrow = 3 * bw + 2, cs = nrow * 36, npair = na * (na + 1) / 2;
   const double* __restrict__ C0 = Ball + sg.base + (long)sg.n_int * cs;  // corner columns
@@ -490,10 +494,11 @@ __global__ __launch_bounds__(256) void k_bseg_corner_add(double* __restrict__ Ba
 // to x_out [Cf][6].
 __global__ __launch_bounds__(64) void k_bseg_backsolve(const double* __restrict__ Ball, const BandedSeg* __restrict__ segs, int bw,
                                                        const int* __restrict__ l2, const double* __restrict__ x2,
-                                                       const LmCtrl* ctrl, double* __restrict__ x_out) {
+                                                       const LmCtrl* ctrl, double* __restrict__ x_out, int b0) {
   extern __shared__ double lds[];
   if (ctrl && ctrl->done) return;
-  const BandedSeg sg = segs[blockIdx.x];
+  const int bseg = b0 + blockIdx.x;  // (b0: the first segment of this rank in the sharded solve, else 0)
+  const BandedSeg sg = segs[bseg];
   const BandedShape sh{sg.n_int + 2 * bw, sg.n_int, bw, 2 * bw, 3 * bw + 2};
   const double* __restrict__ B = Ball + sg.base;
   const int lane = threadIdx.x;
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(64) void k_bseg_backsolve(const double* __restrict_
   double* part = xa + sh.na * 6;
   for (int w = lane; w < sh.na * 6; w += 64) {
     const int a = w / 6, e = w - 6 * a;
-    const double v = x2[6L * l2[(long)blockIdx.x * sh.na + a] + e];
+    const double v = x2[6L * l2[(long)bseg * sh.na + a] + e];
     xa[w] = v;
     if (a < bw) x_out[6L * (sg.first - bw + a) + e] = v;  // the left separator's cameras
   }

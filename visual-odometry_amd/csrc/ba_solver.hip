@@ -48,6 +48,7 @@ struct Rccl {
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclBroadcast) Broadcast = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclReduce) Reduce = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -69,7 +70,7 @@ Rccl* rccl_load() {
   r.name = reinterpret_cast<decltype(r.name)>(dlsym(lib, "nccl" #name));      \
   if (!r.name) return nullptr;
   RCCL_SYM(GetUniqueId) RCCL_SYM(CommInitRank) RCCL_SYM(CommDestroy) RCCL_SYM(CommCount) RCCL_SYM(CommUserRank)
-  RCCL_SYM(AllReduce) RCCL_SYM(Broadcast)
+  RCCL_SYM(AllReduce) RCCL_SYM(Broadcast) RCCL_SYM(Reduce)
   RCCL_SYM(AllGather) RCCL_SYM(GroupStart) RCCL_SYM(GroupEnd) RCCL_SYM(GetErrorString)
 #undef RCCL_SYM
   r.lib = lib;
@@ -153,6 +154,11 @@ struct ba_handle {
   size_t banded_lds = 0;
   // two-level (segmented) variant: P segments in parallel + a level-2 system of the separators
   int bseg_P = 0, bseg_bw = 0;
+  // several ranks, BA_SHARDED_SOLVE=1: every rank eliminates the segments [sh_q0, sh_q1) of the two-level banded solver
+  bool sharded = false;
+  int sh_q0 = 0, sh_q1 = 0;
+  std::vector<int> h_cam_owner;       // rank that adds the damping and the rhs of a free camera
+  const int* cam_owner = nullptr;
   long bseg_base2 = 0, bseg_total = 0;
   size_t bseg_lds = 0;
   const BandedSeg* bseg_segs = nullptr;
@@ -648,7 +654,9 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
     launch_timed(h, KT_GATHER, k_gather_S, d.nu + (d.C - d.Cf), 256, d, mode, lam, o.min_diag, fused_precond, csum_arg);
   else launch_timed(h, KT_GATHER, k_reduce_S, grid_for(d.s_slab_stride + 27L * d.C), 256, d, mode);
   const size_t red_count = (size_t)d.nu * 36 + (size_t)6 * d.Cf + (size_t)27 * d.C;
-  if (h->world > 1)  // the one exchange step of the path: partial S, reduced rhs, U / gc summed over the shards
+  if (h->world > 1 && h->sharded)  // sharded reduced solve: only rhs | U, gc are summed everywhere; S travels by segment below
+    NCCL_TRY(h, h->rccl->AllReduce(d.rhs, d.rhs, (size_t)6 * d.Cf + (size_t)27 * d.C, ncclDouble, ncclSum, h->comm, h->stream));
+  else if (h->world > 1)  // the one exchange step of the path: partial S, reduced rhs, U / gc summed over the shards
     NCCL_TRY(h, h->rccl->AllReduce(d.S, d.S, red_count, ncclDouble, ncclSum, h->comm, h->stream));
   if (d.prior.n > 0) {  // the pose prior's Gauss-Newton terms, into the assembled system
     k_prior_add<<<1, 256, 0, h->stream>>>(d, mode ? nullptr : (const double*)d.poses_buf[0]);  // explicit mode: the point that ba_debug_linearization staged
@@ -701,19 +709,41 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
     const int P = h->bseg_P, bw = h->bseg_bw;
     double* Ball = h->banded_B;
     HIP_TRY(h, hipMemsetAsync(Ball, 0, (size_t)h->bseg_total * sizeof(double), h->stream));
+    // Sharded (several ranks, BA_SHARDED_SOLVE=1): every rank scatters its PARTIAL S; the damping and the (all-reduced)
+    // right-hand side of a camera are added by the rank that owns it.  The segments then travel to their owners (one
+    // reduce per rank, grouped: half the volume of the all-reduce they replace), each rank eliminates the interiors of
+    // its own segments, and what they leave on the separators is summed over the ranks together with the separators'
+    // own blocks (an all-reduce of the small level-2 system).
+    const int q0 = h->sharded ? h->sh_q0 : 0, q1 = h->sharded ? h->sh_q1 : P;
     launch_timed(h, KT_PCG, k_bseg_assemble, grid_for((long)d.nu * 36 + 6L * d.Cf), 256, d, Ball, h->bseg_dst, h->bseg_tr,
-                 h->bseg_rdst, lam, o.min_diag, mode);
-    launch_timed_lds(h, KT_PCG, k_bseg_factor, P, BND_THREADS, h->bseg_lds, Ball, h->bseg_segs, bw, ctrl, d.scal + SC_BADV);
+                 h->bseg_rdst, lam, o.min_diag, mode, h->sharded ? h->cam_owner : nullptr, h->rank);
+    if (h->sharded) {
+      const int per = P / h->world;
+      NCCL_TRY(h, h->rccl->GroupStart());
+      for (int t = 0; t < h->world; ++t) {
+        const long lo = h->h_segs[(size_t)t * per].base;
+        const long hi = t + 1 < h->world ? h->h_segs[(size_t)(t + 1) * per].base : h->bseg_base2;
+        NCCL_TRY(h, h->rccl->Reduce(Ball + lo, Ball + lo, (size_t)(hi - lo), ncclDouble, ncclSum, t, h->comm, h->stream));
+      }
+      NCCL_TRY(h, h->rccl->GroupEnd());
+    }
+    launch_timed_lds(h, KT_PCG, k_bseg_factor, q1 - q0, BND_THREADS, h->bseg_lds, Ball, h->bseg_segs + q0, bw, ctrl, d.scal + SC_BADV);
     for (int parity = 0; parity < 2; ++parity)
-      launch_timed(h, KT_PCG, k_bseg_corner_add, P / 2, 256, Ball, h->bseg_segs, bw, parity, h->bseg_cdst, h->bseg_ctr,
-                   h->bseg_crdst, ctrl);
+      launch_timed(h, KT_PCG, k_bseg_corner_add, (q1 - q0 + 1) / 2, 256, Ball, h->bseg_segs, bw, parity, h->bseg_cdst, h->bseg_ctr,
+                   h->bseg_crdst, ctrl, q0, q1);
+    if (h->sharded)
+      NCCL_TRY(h, h->rccl->AllReduce(Ball + h->bseg_base2, Ball + h->bseg_base2, (size_t)(h->bseg_total - h->bseg_base2), ncclDouble,
+                                     ncclSum, h->comm, h->stream));
     launch_timed_lds(h, KT_PCG, k_banded_factor, 1, BND_THREADS, h->banded_lds, Ball + h->bseg_base2, sh2, ctrl,
                      d.scal + SC_BADV);
     launch_timed_lds(h, KT_PCG, k_banded_backsolve, 1, 64,
                      (size_t)((sh2.bw + 1 + std::max(sh2.na, 1)) * 6 + 66) * sizeof(double),
                      (const double*)(Ball + h->bseg_base2), sh2, ctrl, h->bseg_x2);
-    launch_timed_lds(h, KT_PCG, k_bseg_backsolve, P, 64, (size_t)((bw + 1 + 2 * bw) * 6 + 66) * sizeof(double),
-                     (const double*)Ball, h->bseg_segs, bw, h->bseg_l2, (const double*)h->bseg_x2, ctrl, d.dc);
+    if (h->sharded) HIP_TRY(h, hipMemsetAsync(d.dc, 0, (size_t)6 * d.Cf * sizeof(double), h->stream));
+    launch_timed_lds(h, KT_PCG, k_bseg_backsolve, q1 - q0, 64, (size_t)((bw + 1 + 2 * bw) * 6 + 66) * sizeof(double),
+                     (const double*)Ball, h->bseg_segs, bw, h->bseg_l2, (const double*)h->bseg_x2, ctrl, d.dc, q0);
+    // every camera's step has exactly one writer among the ranks (zeros elsewhere): the sum hands every rank the same bits
+    if (h->sharded) NCCL_TRY(h, h->rccl->AllReduce(d.dc, d.dc, (size_t)6 * d.Cf, ncclDouble, ncclSum, h->comm, h->stream));
     *pcg_iters = -1;
     return BA_OK;
   }
@@ -1185,7 +1215,7 @@ int ba_problem_info(const ba_handle* h, int64_t* info) {
                                     h->bcr_solve ? h->bcr_plan.m / 6 : h->banded_solve ? h->bshape.bw : 0,
                                     h->bcr_solve ? h->bcr_plan.n_levels : h->banded_solve ? h->bshape.na : 0,
                                     h->bcr_solve ? h->bcr_plan.N : h->bseg_P,
-                                    h->Cf, h->L_obs, (h->lin_cpw > 0 ? 1 : 0) | (h->flat_chunks > 0 && h->use_flat_backsub ? 2 : 0) | (h->matrix_free ? 4 : 0) | (h->lin_win ? 8 : 0) | (h->lin_rows ? 16 : 0),
+                                    h->Cf, h->L_obs, (h->lin_cpw > 0 ? 1 : 0) | (h->flat_chunks > 0 && h->use_flat_backsub ? 2 : 0) | (h->matrix_free ? 4 : 0) | (h->lin_win ? 8 : 0) | (h->lin_rows ? 16 : 0) | (h->sharded ? 32 : 0),
                                     h->d.n_comp, (int64_t)h->d.n_urows};
   for (int i = 0; i < BA_INFO_COUNT; ++i) info[i] = v[i];
   return BA_OK;
@@ -1955,6 +1985,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
     // blocks that lie outside the last na rows; the cheapest window wins
     h->banded_solve = false;
     h->bseg_P = 0;
+    h->sharded = false;
     // best (bw, na) for n cameras whose upper-triangle blocks are `pairs` (r <= c); false if nothing fits the LDS
     auto choose_shape = [](int n, const std::vector<std::pair<int, int>>& pairs, int* bw_out, int* na_out) {
       std::vector<int> reach(n, 0);  // reach[c] = max (c - r) over the blocks of column c, then prefix maximum
@@ -1992,6 +2023,14 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
         for (int s2 = 0; s2 < nu; ++s2) bwr = std::max(bwr, std::min(ucol[s2] - urow[s2], Cf - (ucol[s2] - urow[s2])));
         int P = env_int("BA_BSEG_P", (int)std::lround(std::sqrt((double)Cf / (2.0 * std::max(bwr, 1)))));
         P = std::min(P & ~1, 256);
+        // Several ranks with BA_SHARDED_SOLVE=1 (opt-in: DESIGN.md section 7): the segments are dealt out to the ranks in
+        // contiguous runs, so their number is a multiple of the ranks (and even: the parity rule of k_bseg_corner_add)
+        const bool want_sharded = h->world > 1 && env_int("BA_SHARDED_SOLVE", 0) != 0;
+        if (want_sharded) {
+          int per = std::max(1, (P + h->world / 2) / h->world);
+          if ((per * h->world) & 1) ++per;
+          P = per * h->world;
+        }
         bool two = env_int("BA_BSEG", 1) && bwr >= 1 && P >= 4 && Cf / P >= 3 * bwr + 1 && 3 * bwr + 2 <= BND_MAX_NROW &&
                    (long)(3 * bwr + 1) * (3 * bwr + 2) <= BND_MAX_LDS_BLOCKS;
         if (two) {
@@ -2078,6 +2117,14 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
             }
             if (two) {
               h->bseg_P = P; h->bseg_bw = bw; h->bseg_base2 = base2; h->bseg_total = base2 + (long)n2 * cs2;
+              if (want_sharded && P % h->world == 0 && P <= 256) {
+                const int per = P / h->world;
+                h->sharded = true;
+                h->sh_q0 = h->rank * per;
+                h->sh_q1 = h->sh_q0 + per;
+                h->h_cam_owner.assign(Cf, 0);
+                for (int f = 0; f < Cf; ++f) h->h_cam_owner[f] = (seg_of[f] >= 0 ? seg_of[f] : -1 - seg_of[f]) / per;
+              }
               h->bseg_lds = (size_t)(bw + 1 + na_s) * nrow_s * 36 * sizeof(double) + 1024;
               h->bshape = sh2;
               HIP_TRY(h, hipFuncSetAttribute((const void*)k_bseg_factor, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2095,7 +2142,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
     // ---- block cyclic reduction (ba_bcr.h): super-blocks of >= bwr consecutive cameras make S block tridiagonal (cyclic)
     h->bcr_solve = false;
     if (Cf > 0 && !h->comp_solve && (want == BA_SOLVER_CYCLIC_REDUCTION || (want == BA_SOLVER_AUTO && h->banded_solve)) &&
-        env_int("BA_BCR", 1)) {
+        env_int("BA_BCR", 1) && !h->sharded) {
       int bwr = 0;
       for (int s2 = 0; s2 < nu; ++s2) bwr = std::max(bwr, std::min(ucol[s2] - urow[s2], Cf - (ucol[s2] - urow[s2])));
       // Two ways to cut the cameras into super-blocks, the first that keeps S block tridiagonal wins:
@@ -2306,6 +2353,8 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
         (rc = dev_upload(h, &h->bseg_cdst, h->h_cdst)) || (rc = dev_upload(h, &h->bseg_ctr, h->h_ctr)) ||
         (rc = dev_upload(h, &h->bseg_crdst, h->h_crdst)) || (rc = dev_upload(h, &h->bseg_l2, h->h_l2)))
       return rc;
+    h->cam_owner = nullptr;
+    if (h->sharded && (rc = dev_upload(h, &h->cam_owner, h->h_cam_owner))) return rc;
   } else if (h->banded_solve && (rc = dev_alloc(h, &h->banded_B, (size_t)Cf * h->bshape.nrow * 36))) {
     return rc;
   }
