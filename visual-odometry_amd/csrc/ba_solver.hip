@@ -972,9 +972,11 @@ int lm_solve(ba_handle* h, ba_report* rep) {
   // One batch AHEAD: the host puts the next batch into the stream before it waits for the current one, so the GPU never
   // idles through the round trip (k_lm_decide -> pinned memory -> host -> six launches: 8 us per iteration at config
   // 2, the only gap of an iteration in the kernel trace).  The batch that turns out to follow termination exits at the
-  // first instruction of each kernel (~15 us once per solve).  One GPU only: with several ranks that batch would also
-  // run its collectives.
-  const bool ahead = h->world == 1 && !h->coarse && env_int("BA_LM_AHEAD", 1) != 0;
+  // first instruction of each kernel (~15 us once per solve).  With several ranks that batch also runs its collectives
+  // (once per solve, on every rank alike: the LM state is replicated bit for bit, so every rank's host sees `done` after
+  // the same batch and has enqueued the same number of batches by then; BA_LM_AHEAD=0 on every rank restores the
+  // lock-step order).
+  const bool ahead = !h->coarse && env_int("BA_LM_AHEAD", 1) != 0;
   if (o.max_iters > 0 && (rc = enqueue_batch())) return rc;
   int wait_end = enq;  // the host waits until iterations [0, wait_end) have decided
   while (wait_end > 0) {
