@@ -300,7 +300,7 @@ def packed_to_reference_scene(sc):
     return cam, feats, poses, Landmarks3D(sc["points_guess"].copy(), ids)
 
 
-def run_reference_on_packed(sc, shipped: bool, polish_dense: bool):
+def run_reference_on_packed(sc, shipped: bool, polish_dense: bool, numpy_polish_iters: int = 0):
     """The reference on a scene of the product's generator.  shipped: BundleAdjustment.optimize itself
     (bundle_adjustment.py:156-288, least_squares captured); else the lean path of SURVEY.md Appendix C (the reference's
     residual_function + the reference's kwargs + a vectorised mask: optimize() prints the dense mask and cannot run at
@@ -336,6 +336,21 @@ def run_reference_on_packed(sc, shipped: bool, polish_dense: bool):
     out.update(x0=x0, ref_x=res.x, ref_cost=np.array(res.cost), ref_status=np.array(res.status), ref_nfev=np.array(res.nfev),
                ref_njev=np.array(res.njev), ref_optimality=np.array(res.optimality))
     t0 = time.perf_counter()
+    if numpy_polish_iters > 0:
+        # scipy's dense exact trust region does not fit this size, and its LSMR variant at 1e-12 needs hours on a flat
+        # valley (tried: 2 h 20 min without finishing): the tight-tolerance minimum comes from the numpy LM with direct
+        # solves, started at the reference's result, as for the full-size ring fixtures (the chain of DESIGN.md section 2)
+        C = len(sc["poses_guess"])
+        poses = np.vstack([sc["poses_guess"][0][None], res.x[: 7 * (C - 1)].reshape(-1, 7)])
+        poses[:, 3:7] /= np.linalg.norm(poses[:, 3:7], axis=1, keepdims=True)
+        pts = res.x[7 * (C - 1):].reshape(-1, 3)
+        opt = lm.LMOptions(max_iters=numpy_polish_iters, ftol=1e-12, gtol=1e-9, xtol=1e-14)
+        P, X, rep = lm.lm_solve(poses, pts, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"], opt=opt, uniform_tracks=True)
+        out.update(polished_cost=np.array(rep.cost), polished_x=np.concatenate([P[1:].reshape(-1), X.reshape(-1)]),
+                   polished_status=np.array(rep.status), polished_nfev=np.array(rep.iterations),
+                   polished_optimality=np.array(rep.grad_inf), polished_by=np.array("oracle/lm_schur_numpy direct, ftol 1e-12"),
+                   polished_seconds=np.array(time.perf_counter() - t0))
+        return out
     pol = orc.polish(res.x, *a, dense=polish_dense, max_nfev=300 if polish_dense else 400)
     out.update(polished_cost=np.array(pol.cost), polished_x=pol.x, polished_status=np.array(pol.status),
                polished_nfev=np.array(pol.nfev), polished_optimality=np.array(pol.optimality),
@@ -367,7 +382,7 @@ def round3_fixtures(only):
     if not only or name in only:
         t0 = time.time()
         sc = scenes.ring_scene(120, 6000, 5, spacing_of=10000)
-        out = run_reference_on_packed(sc, shipped=False, polish_dense=False)
+        out = run_reference_on_packed(sc, shipped=False, polish_dense=False, numpy_polish_iters=3000)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **{k: sc[k] for k in keys}, **out)
         print(f"{name}: ref cost {float(out['ref_cost']):.12g} status {int(out['ref_status'])} nfev {int(out['ref_nfev'])} in "
               f"{float(out['ref_seconds']):.0f}s  polished {float(out['polished_cost']):.12g} (status {int(out['polished_status'])}, "
