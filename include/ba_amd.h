@@ -278,7 +278,8 @@ int ba_debug_linearization(ba_handle* h, const double* poses, const double* poin
 /* Device time per kernel class, measured with HIP events on the solver's own stream during the
  * solves since the last ba_set_problem (needs opt.profile_kernels = 1).  Classes:
  * 0 k_linearize*, 1 k_schur*, 2 k_backsub, 3 k_cost, 4 the reduced camera solve (one-workgroup PCG, or every launch of
- * the Cholesky solvers), 5 other (k_block_precond, k_triangulate), 6 k_gather_S / k_reduce_S, 7 k_lm_decide.
+ * the Cholesky solvers), 5 other (k_block_precond, k_triangulate), 6 k_gather_S / k_reduce_S, 7 k_fold_stats + k_lm_decide
+ * (two launches per LM iteration since version 101: the average is over both).
  * No reference counterpart (bench.py's roofline figures). */
 #define BA_KERNEL_CLASSES 8
 int ba_get_kernel_times(ba_handle* h, double* total_ms, int32_t* launches);
