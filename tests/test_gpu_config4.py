@@ -52,6 +52,58 @@ def test_config4_geometry_lockstep_with_oracle():
     assert abs(cost_eval - full["cost"]) <= 1e-12 * full["cost"]
 
 
+def test_config4_geometry_arc_against_the_reference(golden):
+    """The same 120-camera arc pinned against THE REFERENCE (round 3; tests/golden/arc_120x6000.npz, oracle/make_golden.py:
+    the reference's residual_function driven by the reference's least_squares settings, bundle_adjustment.py:201-219,
+    218 evaluations / 200 s, cost 4928.5457; and the numpy LM with direct solves run on from there to ftol 1e-12,
+    725 iterations, cost 4922.0099 -- scipy's own tight-tolerance variants do not finish on this valley: dense exact
+    trust region: 9 GB Jacobian; LSMR at 1e-12: stopped after 2 h 20 min).
+    What holds on a valley this flat, and is asserted:
+      * the generator rebuilds the fixture's scene bit for bit; the residuals at the guess are the reference's (1e-9 px);
+        the cost of the REFERENCE'S OWN RESULT, evaluated on the GPU, is the reference's cost (1e-12): same objective;
+      * started at the reference's result, the solver reaches the polished minimum from there, two-sided 1e-6
+        (measured 4e-9);
+      * started at the guess with the defaults it ends BELOW the reference's cost (4926.44 < 4928.55), and with exact
+        linear solves and ftol 1e-12 below the polished value too (4919.76 < 4922.01: the valley goes on);
+      * at the reference's own tolerances it stops where an LM step first gains less than 1e-6 of the cost: 4931.42,
+        5.8e-4 ABOVE the reference's 4928.55 (scipy's trust region takes 218 evaluations to get there, this LM stops after
+        113 iterations): asserted within 1e-3, not one-sided.  The minimiser on this geometry is path-dependent at the
+        1e-3 level for every solver involved; the objective is pinned to 1e-12."""
+    g = golden("arc_120x6000")
+    sc = scenes.ring_scene(120, 6000, 5, spacing_of=10000)
+    assert np.array_equal(g["obs_cam"], sc["obs_cam"]) and np.array_equal(g["obs_pt"], sc["obs_pt"])
+    for k in ("obs_uv", "poses_guess", "points_guess"):
+        np.testing.assert_array_equal(g[k], sc[k])
+    C, L = 120, 6000
+    a = (sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+    ref, pol = float(g["ref_cost"]), float(g["polished_cost"])
+    assert int(g["ref_status"]) == 2 and pol < ref
+    ref_poses = np.vstack([sc["poses_guess"][0][None], g["ref_x"][: 7 * (C - 1)].reshape(-1, 7)])
+    ref_pts = g["ref_x"][7 * (C - 1):].reshape(-1, 3)
+    with _native.Solver() as s:
+        s.set_problem(C, L, *a)
+        r0, _, _ = s.evaluate(sc["poses_guess"], sc["points_guess"])
+        np.testing.assert_allclose(r0, g["residual_at_x0"], rtol=0, atol=1e-9)
+        _, cost_at_ref, _ = s.evaluate(ref_poses, ref_pts, want_residuals=False)
+        assert abs(cost_at_ref - ref) <= 1e-12 * ref, (cost_at_ref, ref)
+        _, _, dflt = s.solve(sc["poses_guess"], sc["points_guess"])
+    assert dflt["status"] in (1, 2, 3) and dflt["cost"] <= ref * (1 + 1e-6), (dflt["cost"], ref)
+    with _native.Solver(ftol=1e-12, max_iters=4000) as s:
+        s.set_problem(C, L, *a)
+        _, _, on = s.solve(ref_poses, ref_pts)
+    assert on["status"] in (1, 2, 3) and abs(on["cost"] - pol) <= 1e-6 * pol, (on["cost"], pol)
+    with _native.Solver(ftol=1e-12, max_iters=4000, linear_solver=3) as s:
+        s.set_problem(C, L, *a)
+        _, _, exact = s.solve(sc["poses_guess"], sc["points_guess"])
+    assert exact["status"] in (1, 2, 3) and exact["bad_pivots"] == 0 and exact["cost"] <= pol * (1 + 1e-6), (exact["cost"], pol)
+    with _native.Solver(ftol=1e-6, xtol=1e-6, gtol=1e-6) as s:
+        s.set_problem(C, L, *a)
+        _, _, at_ref_tol = s.solve(sc["poses_guess"], sc["points_guess"])
+    assert at_ref_tol["status"] in (1, 2, 3) and abs(at_ref_tol["cost"] - ref) <= 1e-3 * ref, (at_ref_tol["cost"], ref)
+    print(f"arc 120 x 6000: reference {ref:.4f}, polished {pol:.4f}; GPU defaults {dflt['cost']:.4f} ({dflt['iterations']} it), "
+          f"from the reference's result {on['cost']:.6f}, exact solves {exact['cost']:.4f}, reference tolerances {at_ref_tol['cost']:.4f}")
+
+
 @pytest.fixture(scope="module")
 def config4():
     sc = scenes.ring_scene(10000, 2000000, 5)
