@@ -21,6 +21,7 @@
 #include <numeric>
 #include <memory>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <limits>
 #include <mutex>
@@ -1329,7 +1330,13 @@ int ba_set_problem(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_t*
   // rank keeps the problem unless every rank built it
   int rc = agree_status(h, validate_problem(h, C, L, n, obs_cam, obs_pt, obs_uv, intr, fixed_in), "set_problem");
   if (rc) return rc;
-  rc = set_problem_impl(h, C, L, n, obs_cam, obs_pt, obs_uv, intr, fixed_in);
+  try {  // (the tables are std::vectors, built on several host threads: no exception may cross the C boundary)
+    rc = set_problem_impl(h, C, L, n, obs_cam, obs_pt, obs_uv, intr, fixed_in);
+  } catch (const std::bad_alloc&) {
+    rc = fail(h, BA_ERR_NOMEM, "set_problem: out of host memory while building the index tables");
+  } catch (const std::exception& e) {
+    rc = fail(h, BA_ERR_DEVICE, "set_problem: %s", e.what());
+  }
   if (!h->agree_failed) rc = agree_status(h, rc, "set_problem");
   if (rc) free_problem(h);
   return rc;
@@ -1490,10 +1497,15 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
     list->swap(h->pending);
     EarlyUpload* eu = &early;
     const int dev = h->device;
-    early.th = std::thread([list, eu, dev] {
+    auto work = [list, eu, dev] {
       if ((eu->err = hipSetDevice(dev)) != hipSuccess) return;
       eu->err = commit_list(*list, &eu->base);
-    });
+    };
+    try {
+      early.th = std::thread(work);
+    } catch (const std::system_error&) {  // no thread to be had: the copies run here, before the tables
+      work();
+    }
   }
   // ---- block pattern of the reduced camera system (upper triangle over free cameras)
   std::vector<int64_t> keys;
@@ -2345,7 +2357,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
   queue_alloc(h, &h->poses_init, (size_t)7 * C); queue_alloc(h, &d.pts_buf[0], (size_t)3 * L);
   queue_alloc(h, &d.pts_buf[1], (size_t)3 * L); queue_alloc(h, &h->pts_init, (size_t)3 * L);
   if ((rc = dev_commit(h))) return rc;
-  early.th.join();
+  if (early.th.joinable()) early.th.join();
   if (early.base) { h->allocs.push_back(early.base); early.kept = true; }
   HIP_TRY(h, early.err);
   lap("uploads + state allocation");

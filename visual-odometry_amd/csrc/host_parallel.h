@@ -7,7 +7,10 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <exception>
 #include <memory>
+#include <mutex>
+#include <system_error>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -43,15 +46,34 @@ inline int threads_for(long items, long grain = 32768) {
   return (int)std::max<long>(1, std::min<long>(want, items / std::max<long>(grain, 1)));
 }
 
-// fn(t, T) on T threads (t = 0 runs on the caller's thread); returns when all are done
+// fn(t, T) on T threads (t = 0 runs on the caller's thread); returns when all are done.  An exception in a part
+// (std::bad_alloc from a table that does not fit) is carried to the caller and thrown there after every thread has
+// been joined: ba_set_problem turns it into a status.
 template <class F>
 void run(int T, F&& fn) {
   if (T <= 1) { fn(0, 1); return; }
+  std::exception_ptr first;
+  std::mutex guard;
+  auto part = [&](int t) {
+    try {
+      fn(t, T);
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(guard);
+      if (!first) first = std::current_exception();
+    }
+  };
   std::vector<std::thread> th;
   th.reserve((size_t)T - 1);
-  for (int t = 1; t < T; ++t) th.emplace_back([&fn, t, T] { fn(t, T); });
-  fn(0, T);
+  for (int t = 1; t < T; ++t) {
+    try {
+      th.emplace_back(part, t);
+    } catch (const std::system_error&) {  // the process may not start another thread: this part runs here
+      part(t);
+    }
+  }
+  part(0);
   for (auto& x : th) x.join();
+  if (first) std::rethrow_exception(first);
 }
 
 // [begin, end) of part t of T over `count` items
