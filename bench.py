@@ -44,7 +44,7 @@ PROFILE_ROUND = "r03"
 def algorithmic_bytes(kernel: str, nobs: int, n_lm: int, n_cam: int, info: dict) -> float:
     """Bytes one launch must move (DESIGN.md 'Kernels').  W travels factored (12 doubles = 96 B per observation instead
     of SURVEY.md section 8d's 144 B: csrc/ba_kernels.h, w_from_j), so these figures are below the survey's."""
-    mf = info.get("linearize_flat", 0) & 4  # matrix-free path (>= 2 M observations; >= 1 M with short tracks): W is rebuilt, never stored
+    mf = info.get("linearize_flat", 0) & 4  # matrix-free path (>= 2 M observations): W is rebuilt, never stored
     # round 3 (k_linearize_rows): U | gc leave the linearisation as one row of 27 doubles per (chunk, camera) instead of
     # atomics into slabs; the fold blocks at the end of the Schur launch read them and write the slabs the gather sums
     rows = 216.0 * info.get("u_rows", 0)
@@ -295,6 +295,9 @@ def run_workload(args, name, steps, warmup, dist, rank, world, local_rank, kerne
                     "whole_iteration": {"algorithmic_bytes": it_bytes, "us": it_us,
                                         "GBps": it_bytes / (it_us * 1e-6) / 1e9,
                                         "frac": it_bytes / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                        # SURVEY.md 8(d)'s own per-unit figure, whatever this layout moves: 480 B per
+                                        # observation + 384 B per landmark + 900 B per camera per accepted iteration
+                                        "frac_survey_8d_bytes": (480.0 * nobs + 384.0 * L_local + 900.0 * C) / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                         "note": "SURVEY.md 8(d) bytes of one accepted LM iteration / (solve wall time / "
                                                 "iterations, rejected ones included)"},
                     "per_kernel": per_kernel}

@@ -1880,13 +1880,13 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
   lap("schur tables");
   // W is not stored when both of its readers can rebuild it (the staged Schur kernel and the flat back-substitution)
   // and the problem is large enough for the traffic to matter: measured per LM iteration, stored / rebuilt: config 2
-  // (0.2 M observations) 135 / 137 us, config 3 (1 M) 395 / 398 us (round 3: 270 / 266 us, so config 3 rebuilds now; 1024
-  // windows of 1000 observations with tracks of ten: 1.75 / 1.89 ms per solve, so long tracks switch at 2 M),
+  // (0.2 M observations) 135 / 137 us, config 3 (1 M) 395 / 398 us (round 3: 270 / 266 us; 1024 windows of 1000
+  // observations with tracks of ten: 1.75 / 1.89 ms per solve: the switch stays at 2 M),
   // config 4 (10 M) 1.89 / 1.76 ms (round 3: 1.46 / 1.28 ms) (the linearisation
   // loses its 96 B per observation of stores, the back-substitution its loads; the Schur kernel, which is not bound by
   // memory, pays 8-14 % for the arithmetic).  Rebuilding also frees 96 B per observation (0.96 GB at config 4).
   h->matrix_free = h->schur_cpb > 0 && h->flat_chunks > 0 && h->use_flat_backsub &&
-                   env_int("BA_MATRIX_FREE", (n >= 2000000 || (n >= 1000000 && h->g_schur <= 16)) ? 1 : 0) != 0;
+                   env_int("BA_MATRIX_FREE", n >= 2000000 ? 1 : 0) != 0;
   // privatised slabs: as many copies as fit a fixed budget, so that few atomics share an address
   {
     const size_t u_bytes = (size_t)C * 27 * sizeof(double);
