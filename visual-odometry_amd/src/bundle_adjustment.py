@@ -173,16 +173,24 @@ class BundleAdjustment:
         image_width = image_features_list[0].image_width
         image_height = image_features_list[0].image_height
         starts = np.searchsorted(obs_cam, np.arange(n_cams + 1))
+        # same arithmetic as CameraPose.transform_points_world_to_camera per image ((P - t) @ R on that image's slice),
+        # then ONE call of the camera model's project over all observations (it works point by point: same bits as a
+        # call per image, without fifty rounds of argument checks)
+        pts_obs = points[obs_pt]
+        pts_cam = np.empty_like(pts_obs)
+        for i in range(n_cams):
+            if starts[i] < starts[i + 1]:
+                pose = optimized_camera_poses[i]
+                pts_cam[starts[i]:starts[i + 1]] = (pts_obs[starts[i]:starts[i + 1]] - pose.position.reshape(1, 3)) @ pose.rotation_matrix
+        uv_all = camera_model.project(pts_cam) if len(pts_cam) else np.zeros((0, 2))
         optimized_image_features = []
         for i, feats in enumerate(image_features_list):
-            sel = slice(starts[i], starts[i + 1])
             if starts[i] == starts[i + 1]:
                 optimized_image_features.append(feats)
                 continue
-            pts_cam = optimized_camera_poses[i].transform_points_world_to_camera(points[obs_pt[sel]])
             optimized_image_features.append(
                 ImageFeatures(feats.get_timestamp(), feats.get_camera_id(), image_width, image_height,
-                              Features2D(camera_model.project(pts_cam), feats.get_points_2d().get_ids())))
+                              Features2D(uv_all[starts[i]:starts[i + 1]], feats.get_points_2d().get_ids())))
         return optimized_image_features, optimized_points3d, optimized_camera_poses
 
 
