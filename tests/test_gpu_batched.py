@@ -328,3 +328,26 @@ def test_batched_8192_windows_properties():
     assert np.all(np.abs(c - c[0]) <= 1e-9 * c[0])
     print(f"8192 windows: {rep['solve_ms']:.2f} ms, {rep['iterations']} LM iterations, "
           f"{1e3 * rep['solve_ms'] / B:.2f} us per window")
+
+
+def test_batched_solve_repeats_bit_for_bit():
+    """Round 3: the per-window statistics (model decrease, trial cost, trial cheirality count) are per-chunk partial sums
+    added up in a fixed order (comp_store / k_comp_fold_stats), not atomics: two batched solves of the same windows give
+    the same bits (costs, estimates, iteration count), on one handle and on a fresh one."""
+    B, L = 96, 100
+    probs, scs = zip(*[_window(s, L=L) for s in range(B)])
+    intr = scs[0]["intr"]
+    runs = []
+    with _native.Solver() as s:
+        runs.append(s.solve_batched(probs, intr))
+        runs.append(s.solve_batched(probs, intr))
+    with _native.Solver() as s:
+        runs.append(s.solve_batched(probs, intr))
+    P0, X0, c00, c0, rep0 = runs[0]
+    for P, X, c0i, c, rep in runs[1:]:
+        assert rep["iterations"] == rep0["iterations"] and rep["cost"] == rep0["cost"]
+        np.testing.assert_array_equal(c, c0)
+        np.testing.assert_array_equal(c0i, c00)
+        for b in range(B):
+            np.testing.assert_array_equal(P[b], P0[b])
+            np.testing.assert_array_equal(X[b], X0[b])

@@ -91,6 +91,13 @@ struct CompLm {
   double* lam_lm;       // [L_obs] damping per landmark (= lam[lm_comp]): what the streaming kernels load
   const int* lm_comp;   // [L_obs]
   const int* free_comp; // [Cf]
+  // Round 3: the per-component statistics without atomics.  Every chunk of the flat kernels (a wave) stores one entry
+  // per distinct component among its landmarks (usually one): cp_ptr [chunks + 1] / cp_comp [entries] list them,
+  // cp_val [entries][3] = model decrease of the landmark steps | trial cost | trial observations behind a camera;
+  // cc_ptr [n_comp + 1] / cc_ent list a component's entries in ascending order, pose_val [Cf] is the model decrease of
+  // every free camera's step.  k_lm_decide_comp (k_comp_fold_cost for the initial cost) adds them up in that order.
+  const int* cp_ptr; const int* cp_comp; double* cp_val;
+  const int* cc_ptr; const int* cc_ent; double* pose_val;
 };
 
 struct DeviceProblem {
@@ -2581,9 +2588,7 @@ __device__ __forceinline__ void pose_update_block(const DeviceProblem& d, const 
 #pragma unroll
       for (int i = 0; i < 7; ++i) pt[i] = po[i];
       xn = ps[0] * ps[0] + ps[1] * ps[1] + ps[2] * ps[2] + 1.0;
-      if (d.clm.lam) {
-        atomic_add_f64(&d.clm.stat[(long)CL_STRIDE * d.clm.free_comp[f]], gd + 0.5 * dhd);
-      }
+      if (d.clm.lam) d.clm.pose_val[f] = gd + 0.5 * dhd;  // (summed per component, in camera order, by k_lm_decide_comp)
     }
   }
   // one exchange for the five statistics (a block_sum_256 each is two barriers apiece)
@@ -2736,18 +2741,16 @@ __global__ __launch_bounds__(256) void k_backsub(DeviceProblem d, double lam, do
 // camera; it is skipped whenever |dp| < (1 - GUARD_KEEP) zmin (zmin: the landmark's smallest depth, left by the
 // linearisation), which cannot cross a principal plane: the test then costs 8 B per landmark.
 // Algorithmic bytes: those of k_backsub + k_cost minus the second read of the points: 172 B/obs + 152 B/landmark.
-// Add v of every active lane into statistic `slot` of the lane's component: one atomic per wave when the active lanes
-// agree on the component (the usual case: a chunk of 64 observations inside one window), one per lane otherwise.
-// Wave-uniform call.
-__device__ __forceinline__ void comp_add(double* __restrict__ stat, int slot, int comp, bool act, double v) {
-  const unsigned long long m = __ballot(act);
-  if (m == 0) return;
-  const int first = __builtin_amdgcn_readlane(comp, __ffsll((long long)m) - 1);
-  if (__ballot(act && comp != first) == 0) {
-    const double s = wave_sum_dpp(act ? v : 0.0);
-    if ((threadIdx.x & 63) == 0) atomic_add_f64(&stat[(long)CL_STRIDE * first + slot], s);
-  } else if (act) {
-    atomic_add_f64(&stat[(long)CL_STRIDE * comp + slot], v);
+// Per-component statistics of a chunk (a wave) without atomics: for every component on the chunk's list (cp_ptr / cp_comp:
+// the distinct components of its landmarks, as ba_set_problem found them) the sum of v over the active lanes of that
+// component, a wave sum in a fixed order, stored to the entry's slot.  Wave-uniform call; every entry is written in
+// every launch, so nothing needs clearing.
+__device__ __forceinline__ void comp_store(const CompLm& q, int chunk, int slot, int comp, bool act, double v) {
+  const int e0 = q.cp_ptr[chunk], e1 = q.cp_ptr[chunk + 1];
+  for (int e = e0; e < e1; ++e) {
+    const int ce = q.cp_comp[e];
+    const double sum = wave_sum_dpp(act && comp == ce ? v : 0.0);
+    if ((threadIdx.x & 63) == 0) q.cp_val[3L * e + slot] = sum;
   }
 }
 
@@ -2894,7 +2897,7 @@ __global__ __launch_bounds__(256) void k_backsub_flat(DeviceProblem d, double la
     dn = dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];
     xn = P[0] * P[0] + P[1] * P[1] + P[2] * P[2];
   }
-  if (per_comp) comp_add(d.clm.stat, 0, cj, lm_lane, gd + 0.5 * dhd);
+  if (per_comp && have) comp_store(d.clm, c, 0, cj, lm_lane, gd + 0.5 * dhd);
   double cost = 0.0;
   int nbehind = 0, nzero = 0;
   if (with_cost) {
@@ -2916,10 +2919,10 @@ __global__ __launch_bounds__(256) void k_backsub_flat(DeviceProblem d, double la
       nzero = X[2] == 0.0;
       cost = !ROBUST ? 0.5 * (r0 * r0 + r1 * r1) : robust_cost(d.loss, r0) + robust_cost(d.loss, r1);
     }
-    if (per_comp) {
+    if (per_comp && have) {
       const int co = act ? sComp[wave][lm - jb] : 0;
-      comp_add(d.clm.stat, 2, co, act, cost);
-      if (__ballot(act && nbehind != 0) != 0) comp_add(d.clm.stat, 3, co, act, (double)nbehind);
+      comp_store(d.clm, c, 1, co, act, cost);
+      comp_store(d.clm, c, 2, co, act, (double)nbehind);
     }
   }
   // the block's eight statistics in ONE exchange: wave sums (the three counters by ballot), one barrier, eight atomics
@@ -3125,40 +3128,66 @@ __global__ __launch_bounds__(256) void k_comp_init(DeviceProblem d, double lambd
   }
 }
 
-// cost and cheirality count of every component at (poses, pts): a lane per observation
+// cost and cheirality count of every component at (poses, pts): a wave per chunk of the flat kernels, a lane per
+// observation, the chunk's per-component sums into cp_val (slots 1 and 2); k_comp_fold_cost adds up a component's entries
 template <bool ROBUST>
 __global__ __launch_bounds__(256) void k_comp_cost(DeviceProblem d, const double* __restrict__ poses,
-                                                   const double* __restrict__ pts, double* __restrict__ cost_out,
-                                                   double* __restrict__ behind_out) {
-  for (long k0 = (long)blockIdx.x * blockDim.x; k0 < d.n; k0 += (long)gridDim.x * blockDim.x) {
-    const long k = k0 + threadIdx.x;
-    const bool act = k < d.n;
-    double cost = 0.0, nb = 0.0;
-    int comp = 0;
-    if (act) {
-      const int cam = d.o_cam[k], lm = d.o_lm[k];
-      comp = d.clm.lm_comp[lm];
-      const double* ps = poses + 7 * cam;
-      const double P[3] = {pts[3L * lm], pts[3L * lm + 1], pts[3L * lm + 2]};
-      double R[9], X[3], r0, r1;
-      quat_to_R(ps + 3, R);
-      to_camera(R, ps, P, X);
-      reproject(d.K, X, d.o_u[k], d.o_v[k], r0, r1);
-      nb = X[2] <= 0.0 ? 1.0 : 0.0;
-      cost = !ROBUST ? 0.5 * (r0 * r0 + r1 * r1) : robust_cost(d.loss, r0) + robust_cost(d.loss, r1);
-    }
-    // CL_STRIDE-strided adds into plain arrays: slot 0 of a stride-1 "statistic"
-    const unsigned long long m = __ballot(act);
-    if (m == 0) continue;
-    const int first = __builtin_amdgcn_readlane(comp, __ffsll((long long)m) - 1);
-    if (__ballot(act && comp != first) == 0) {
-      const double s = wave_sum_dpp(cost), b = wave_sum_dpp(nb);
-      if ((threadIdx.x & 63) == 0) { atomic_add_f64(&cost_out[first], s); if (b != 0.0) atomic_add_f64(&behind_out[first], b); }
-    } else if (act) {
-      atomic_add_f64(&cost_out[comp], cost);
-      if (nb != 0.0) atomic_add_f64(&behind_out[comp], nb);
-    }
+                                                   const double* __restrict__ pts) {
+  const int c = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (c >= d.n_lin_chunks) return;
+  const int k = d.lin_k[c] + (threadIdx.x & 63);
+  const bool act = k < d.lin_k[c + 1];
+  double cost = 0.0, nb = 0.0;
+  int comp = 0;
+  if (act) {
+    const int cam = d.o_cam[k], lm = d.o_lm[k];
+    comp = d.clm.lm_comp[lm];
+    const double* ps = poses + 7 * cam;
+    const double P[3] = {pts[3L * lm], pts[3L * lm + 1], pts[3L * lm + 2]};
+    double R[9], X[3], r0, r1;
+    quat_to_R(ps + 3, R);
+    to_camera(R, ps, P, X);
+    reproject(d.K, X, d.o_u[k], d.o_v[k], r0, r1);
+    nb = X[2] <= 0.0 ? 1.0 : 0.0;
+    cost = !ROBUST ? 0.5 * (r0 * r0 + r1 * r1) : robust_cost(d.loss, r0) + robust_cost(d.loss, r1);
   }
+  comp_store(d.clm, c, 1, comp, act, cost);
+  comp_store(d.clm, c, 2, comp, act, nb);
+}
+
+// The statistics of every component for k_lm_decide_comp, a wave per component: lane l adds the entries l, l + 64, ...
+// of the component's list and its cameras l, l + 64, ... (ascending), the lanes are added in the fixed order of
+// wave_sum_dpp: stat[w][0] = model decrease, [2] = trial cost, [3] = trial observations behind a camera.  No atomics.
+__global__ __launch_bounds__(256) void k_comp_fold_stats(DeviceProblem d) {
+  if (d.ctrl->done) return;
+  const CompLm& q = d.clm;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= d.n_comp) return;
+  double st0 = 0.0, cost_t = 0.0, behind_t = 0.0;
+  for (int i = q.cc_ptr[w] + lane; i < q.cc_ptr[w + 1]; i += 64) {
+    const long e = q.cc_ent[i];
+    st0 += q.cp_val[3 * e]; cost_t += q.cp_val[3 * e + 1]; behind_t += q.cp_val[3 * e + 2];
+  }
+  for (int i = d.comp_ptr[w] + lane; i < d.comp_ptr[w + 1]; i += 64) st0 += q.pose_val[d.comp_cams[i]];
+  st0 = wave_sum_dpp(st0); cost_t = wave_sum_dpp(cost_t); behind_t = wave_sum_dpp(behind_t);
+  if (lane == 0) {
+    double* st = q.stat + (long)CL_STRIDE * w;
+    st[0] = st0; st[2] = cost_t; st[3] = behind_t;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_comp_fold_cost(DeviceProblem d) {
+  const CompLm& q = d.clm;
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= d.n_comp) return;
+  double cost = 0.0, nb = 0.0;
+  for (int i = q.cc_ptr[w]; i < q.cc_ptr[w + 1]; ++i) {
+    const long e = q.cc_ent[i];
+    cost += q.cp_val[3 * e + 1];
+    nb += q.cp_val[3 * e + 2];
+  }
+  q.cost[w] = cost;
+  q.nbehind[w] = nb;
 }
 
 constexpr int DECIDE_COMP_THREADS = 1024;

@@ -914,11 +914,12 @@ int lm_solve(ba_handle* h, ba_report* rep) {
     note_launch(h);
     if (h->comp_lm) {
       k_comp_init<<<std::min(1024, grid_for(std::max(d.L_obs, d.n_comp))), 256, 0, h->stream>>>(d, o.lambda0);
-      const int grid = std::min(grid_for(d.n), 256 * 16);
+      const int grid = grid_for(h->flat_chunks, 4);
       if (d.loss.kind == LOSS_LINEAR)
-        k_comp_cost<false><<<grid, 256, 0, h->stream>>>(d, (const double*)d.poses_buf[0], (const double*)d.pts_buf[0], d.clm.cost, d.clm.nbehind);
+        k_comp_cost<false><<<grid, 256, 0, h->stream>>>(d, (const double*)d.poses_buf[0], (const double*)d.pts_buf[0]);
       else
-        k_comp_cost<true><<<grid, 256, 0, h->stream>>>(d, (const double*)d.poses_buf[0], (const double*)d.pts_buf[0], d.clm.cost, d.clm.nbehind);
+        k_comp_cost<true><<<grid, 256, 0, h->stream>>>(d, (const double*)d.poses_buf[0], (const double*)d.pts_buf[0]);
+      k_comp_fold_cost<<<grid_for(d.n_comp), 256, 0, h->stream>>>(d);
       note_launch(h);
     }
   }
@@ -955,6 +956,7 @@ int lm_solve(ba_handle* h, ba_report* rep) {
       enqueue_trial(h, -1.0, nullptr, nullptr, nullptr, nullptr);
       if (h->comp_lm) {
         // every connected component decides for itself; the accepted ones move into the current buffers
+        launch_timed(h, KT_DECIDE, k_comp_fold_stats, grid_for(d.n_comp, 4), 256, d);
         launch_timed(h, KT_DECIDE, k_lm_decide_comp, 1, DECIDE_COMP_THREADS, d, h->mirror_dev, enq + 1);
         launch_timed(h, KT_OTHER, k_commit_comp, std::min(2048, grid_for(std::max(d.L_obs, d.Cf))), 256, d);
       } else if (h->world > 1) {
@@ -2407,6 +2409,31 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
         (rc = dev_alloc(h, &d.clm.lam_lm, (size_t)L_obs)) || (rc = dev_upload(h, &d.clm.lm_comp, lm_comp)) ||
         (rc = dev_upload(h, &d.clm.free_comp, free_comp)))
       return rc;
+    // per chunk of the flat kernels: the distinct components of its landmarks, in order of first appearance; and per
+    // component the entries that belong to it, ascending: the fixed order of the per-component sums
+    std::vector<int> cp_ptr(1, 0), cp_comp, cc_ptr(nc + 1, 0), cc_ent;
+    for (int ch = 0; ch < h->flat_chunks; ++ch) {
+      const size_t first = cp_comp.size();
+      for (int j = lin_lm[ch]; j < lin_lm[ch + 1]; ++j) {
+        bool seen = false;
+        for (size_t e = first; e < cp_comp.size() && !seen; ++e) seen = cp_comp[e] == lm_comp[j];
+        if (!seen) cp_comp.push_back(lm_comp[j]);
+      }
+      cp_ptr.push_back((int)cp_comp.size());
+    }
+    for (int cm : cp_comp) cc_ptr[(size_t)cm + 1]++;
+    for (size_t w = 0; w < nc; ++w) cc_ptr[w + 1] += cc_ptr[w];
+    cc_ent.resize(cp_comp.size());
+    {
+      std::vector<int> fill(cc_ptr.begin(), cc_ptr.end() - 1);
+      for (size_t e = 0; e < cp_comp.size(); ++e) cc_ent[(size_t)fill[(size_t)cp_comp[e]]++] = (int)e;
+    }
+    if ((rc = dev_upload(h, &d.clm.cp_ptr, cp_ptr)) || (rc = dev_upload(h, &d.clm.cp_comp, cp_comp)) ||
+        (rc = dev_upload(h, &d.clm.cc_ptr, cc_ptr)) || (rc = dev_upload(h, &d.clm.cc_ent, cc_ent)) ||
+        (rc = dev_alloc(h, &d.clm.cp_val, (size_t)3 * cp_comp.size())) || (rc = dev_alloc(h, &d.clm.pose_val, (size_t)Cf)))
+      return rc;
+    HIP_TRY(h, hipMemset(d.clm.cp_val, 0, std::max<size_t>(1, 3 * cp_comp.size()) * sizeof(double)));
+    HIP_TRY(h, hipMemset(d.clm.pose_val, 0, (size_t)Cf * sizeof(double)));
   }
   d.prior = PriorDev{};
   if (!h->prior.cams.empty()) {
