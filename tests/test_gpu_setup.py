@@ -38,7 +38,12 @@ def test_tables_are_bit_identical_to_the_single_threaded_setup(recorded, cases, 
     for name, case in cases.items():
         got, solver = table_digests.digests(case)
         assert solver == recorded[name]["solver"], name
-        assert [f"{v:016x}" for v in got] == recorded[name]["digests"], (name, threads)
+        want = recorded[name]["digests"]
+        # (the batched case uploads four tables more than round 2 did: the lists behind the fixed-order per-window
+        # statistics; everything round 2 built must still be there, bit for bit, in the same order)
+        extra = 4 if name == "windows_64x10x100" else 0
+        assert len(got) == len(want) + extra, (name, len(got), len(want))
+        assert [f"{v:016x}" for v in got[: len(want)]] == want, (name, threads)
 
 
 def test_tables_of_config4_and_the_setup_time(recorded):
