@@ -332,7 +332,7 @@ def test_batched_8192_windows_properties():
 
 def test_batched_solve_repeats_bit_for_bit():
     """Round 3: the per-window statistics (model decrease, trial cost, trial cheirality count) are per-chunk partial sums
-    added up in a fixed order (comp_store / k_comp_fold_stats), not atomics: two batched solves of the same windows give
+    added up in a fixed order (comp_store / comp_fold_stats_block), not atomics: two batched solves of the same windows give
     the same bits (costs, estimates, iteration count), on one handle and on a fresh one."""
     B, L = 96, 100
     probs, scs = zip(*[_window(s, L=L) for s in range(B)])

@@ -930,11 +930,36 @@ __global__ __launch_bounds__(64) void k_fold_U(DeviceProblem d, int solver_mode)
 // (entry, sub-range), then a fixed tree over the sub-ranges) and adds the result to copy s with plain read-modify-
 // writes (it is the only writer of these slots in its launch).  Replaces eight + four + five fp64 atomics per block.
 // with_lin: the linearisation's partial sums are current (solver mode: the control block knows).
+// The statistics of every component for k_lm_decide_comp (batched solves), a wave per component: lane l adds the entries
+// l, l + 64, ... of the component's list and its cameras l, l + 64, ... (ascending), the lanes are added in the fixed
+// order of wave_sum_dpp: stat[w][0] = model decrease, [2] = trial cost, [3] = trial observations behind a camera.  No
+// atomics.  Runs as the blocks after the first SCAL_SLABS of k_fold_stats' grid (no launch of its own).
+__device__ __forceinline__ void comp_fold_stats_block(const DeviceProblem& d, int block) {
+  const CompLm& q = d.clm;
+  const int w = block * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= d.n_comp) return;
+  double st0 = 0.0, cost_t = 0.0, behind_t = 0.0;
+  for (int i = q.cc_ptr[w] + lane; i < q.cc_ptr[w + 1]; i += 64) {
+    const long e = q.cc_ent[i];
+    st0 += q.cp_val[3 * e]; cost_t += q.cp_val[3 * e + 1]; behind_t += q.cp_val[3 * e + 2];
+  }
+  for (int i = d.comp_ptr[w] + lane; i < d.comp_ptr[w + 1]; i += 64) st0 += q.pose_val[d.comp_cams[i]];
+  st0 = wave_sum_dpp(st0); cost_t = wave_sum_dpp(cost_t); behind_t = wave_sum_dpp(behind_t);
+  if (lane == 0) {
+    double* st = q.stat + (long)CL_STRIDE * w;
+    st[0] = st0; st[2] = cost_t; st[3] = behind_t;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_fold_stats(DeviceProblem d, int solver_mode, int with_lin, int with_bs) {
   __shared__ double red_bs[4][8], red_lin[4][4];
   if (solver_mode) {
     if (d.ctrl->done) return;
     with_lin = with_lin && d.ctrl->need_lin;
+  }
+  if ((int)blockIdx.x >= SCAL_SLABS) {  // (batched solves only: the host adds ceil(n_comp / 4) blocks to the grid)
+    comp_fold_stats_block(d, blockIdx.x - SCAL_SLABS);
+    return;
   }
   with_lin = with_lin && d.n_urows > 0;
   with_bs = with_bs && d.n_bs_blocks > 0;
@@ -3155,39 +3180,18 @@ __global__ __launch_bounds__(256) void k_comp_cost(DeviceProblem d, const double
   comp_store(d.clm, c, 2, comp, act, nb);
 }
 
-// The statistics of every component for k_lm_decide_comp, a wave per component: lane l adds the entries l, l + 64, ...
-// of the component's list and its cameras l, l + 64, ... (ascending), the lanes are added in the fixed order of
-// wave_sum_dpp: stat[w][0] = model decrease, [2] = trial cost, [3] = trial observations behind a camera.  No atomics.
-__global__ __launch_bounds__(256) void k_comp_fold_stats(DeviceProblem d) {
-  if (d.ctrl->done) return;
+__global__ __launch_bounds__(256) void k_comp_fold_cost(DeviceProblem d) {  // a wave per component, as comp_fold_stats_block
   const CompLm& q = d.clm;
   const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (w >= d.n_comp) return;
-  double st0 = 0.0, cost_t = 0.0, behind_t = 0.0;
-  for (int i = q.cc_ptr[w] + lane; i < q.cc_ptr[w + 1]; i += 64) {
-    const long e = q.cc_ent[i];
-    st0 += q.cp_val[3 * e]; cost_t += q.cp_val[3 * e + 1]; behind_t += q.cp_val[3 * e + 2];
-  }
-  for (int i = d.comp_ptr[w] + lane; i < d.comp_ptr[w + 1]; i += 64) st0 += q.pose_val[d.comp_cams[i]];
-  st0 = wave_sum_dpp(st0); cost_t = wave_sum_dpp(cost_t); behind_t = wave_sum_dpp(behind_t);
-  if (lane == 0) {
-    double* st = q.stat + (long)CL_STRIDE * w;
-    st[0] = st0; st[2] = cost_t; st[3] = behind_t;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_comp_fold_cost(DeviceProblem d) {
-  const CompLm& q = d.clm;
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= d.n_comp) return;
   double cost = 0.0, nb = 0.0;
-  for (int i = q.cc_ptr[w]; i < q.cc_ptr[w + 1]; ++i) {
+  for (int i = q.cc_ptr[w] + lane; i < q.cc_ptr[w + 1]; i += 64) {
     const long e = q.cc_ent[i];
     cost += q.cp_val[3 * e + 1];
     nb += q.cp_val[3 * e + 2];
   }
-  q.cost[w] = cost;
-  q.nbehind[w] = nb;
+  cost = wave_sum_dpp(cost); nb = wave_sum_dpp(nb);
+  if (lane == 0) { q.cost[w] = cost; q.nbehind[w] = nb; }
 }
 
 constexpr int DECIDE_COMP_THREADS = 1024;

@@ -825,7 +825,9 @@ void enqueue_trial(ba_handle* h, double lam, const double* poses, const double* 
     launch_cost(h, poses_t, pts_t, SC_COST_T, SC_NBEHIND_T, nullptr);
   // the per-chunk / per-block partial statistics of k_linearize_rows, k_backsub_flat and the pose blocks, summed in a
   // fixed order into the copies of the scalar block (no atomics: the LM path is the same in every run)
-  launch_timed(h, KT_DECIDE, k_fold_stats, SCAL_SLABS, 256, h->d, lam < 0.0 ? 1 : 0, h->lin_rows ? 1 : 0,
+  // (batched solves, solver mode: the per-window sums ride in the same launch, ceil(n_comp / 4) blocks after the first 64)
+  const int comp_blocks = lam < 0.0 && h->comp_lm ? grid_for(h->d.n_comp, 4) : 0;
+  launch_timed(h, KT_DECIDE, k_fold_stats, SCAL_SLABS + comp_blocks, 256, h->d, lam < 0.0 ? 1 : 0, h->lin_rows ? 1 : 0,
                h->flat_chunks > 0 && h->use_flat_backsub ? 1 : 0);
   if (h->d.prior.n > 0) {
     k_prior_trial<<<1, 128, 0, h->stream>>>(h->d, poses, (const double*)poses_t);
@@ -919,7 +921,7 @@ int lm_solve(ba_handle* h, ba_report* rep) {
         k_comp_cost<false><<<grid, 256, 0, h->stream>>>(d, (const double*)d.poses_buf[0], (const double*)d.pts_buf[0]);
       else
         k_comp_cost<true><<<grid, 256, 0, h->stream>>>(d, (const double*)d.poses_buf[0], (const double*)d.pts_buf[0]);
-      k_comp_fold_cost<<<grid_for(d.n_comp), 256, 0, h->stream>>>(d);
+      k_comp_fold_cost<<<grid_for(d.n_comp, 4), 256, 0, h->stream>>>(d);
       note_launch(h);
     }
   }
@@ -956,7 +958,6 @@ int lm_solve(ba_handle* h, ba_report* rep) {
       enqueue_trial(h, -1.0, nullptr, nullptr, nullptr, nullptr);
       if (h->comp_lm) {
         // every connected component decides for itself; the accepted ones move into the current buffers
-        launch_timed(h, KT_DECIDE, k_comp_fold_stats, grid_for(d.n_comp, 4), 256, d);
         launch_timed(h, KT_DECIDE, k_lm_decide_comp, 1, DECIDE_COMP_THREADS, d, h->mirror_dev, enq + 1);
         launch_timed(h, KT_OTHER, k_commit_comp, std::min(2048, grid_for(std::max(d.L_obs, d.Cf))), 256, d);
       } else if (h->world > 1) {
