@@ -1,4 +1,5 @@
-# Debug build of the library with wall_clock64 cuts inside the cyclic-reduction kernels (-DBCR_CLOCKS), one short
+# Debug build of the library with wall_clock64 cuts inside the cyclic-reduction kernels (build it first, in csrc: the Makefile's
+# hipcc line with -DBCR_CLOCKS=1 -o ../lib/libba_amd_clocks.so), one short
 # config-3 solve, the last lines of each kernel's cuts.  Run on the GPU box: bash tools/bcr_clocks.sh
 set -e
 O=gpurun_out/bcr_clocks
