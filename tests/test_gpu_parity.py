@@ -81,7 +81,7 @@ def test_jacobian_blocks_vs_finite_differences(golden, name):
             assert np.abs(Jp[sel][:, :, k] - fd[sel]).max() <= 1e-6 * np.abs(fd[sel]).max()
 
 
-@pytest.mark.parametrize("lin", ["default", "window", "group", "matrix_free", "runs"])
+@pytest.mark.parametrize("lin", ["default", "window", "group", "matrix_free"])
 @pytest.mark.parametrize("name", ["test_scene_convergence", "noisy_10x300"])
 def test_normal_equation_blocks_match_oracle(golden, name, lin, monkeypatch):
     """U, V, W, gradients, Schur complement S, reduced rhs and the LM step against the numpy
@@ -93,8 +93,6 @@ def test_normal_equation_blocks_match_oracle(golden, name, lin, monkeypatch):
     elif lin == "group":
         monkeypatch.setenv("BA_LIN_WIN", "0")
         monkeypatch.setenv("BA_LIN_FLAT", "0")
-    elif lin == "runs":  # k_linearize_rows with runs of up to four chunks per wave (the default only from 65 536 chunks)
-        monkeypatch.setenv("BA_LIN_RUN", "4")
     elif lin == "matrix_free":  # no stored W: the Schur and back-substitution kernels rebuild it (the default from 2 M observations)
         monkeypatch.setenv("BA_MATRIX_FREE", "1")
     g = golden(name)
@@ -148,44 +146,6 @@ def test_windowed_linearisation_on_an_unstructured_scene():
         for k, ref in (("U", U), ("V", V), ("W", W), ("gc", gc), ("gp", gp)):
             np.testing.assert_allclose(out[k], ref, rtol=0, atol=1e-10 * np.abs(ref).max(), err_msg=f"{k} (BA_LIN_WIN={mode})")
     np.testing.assert_allclose(outs["1"]["dc"], outs["0"]["dc"], rtol=0, atol=1e-9 * np.abs(outs["0"]["dc"]).max())
-
-
-@pytest.mark.parametrize("visibility", ["ring", "random"])
-def test_runs_of_chunks_in_the_linearisation(visibility):
-    """k_linearize_rows with a wave per RUN of chunks (BA_LIN_RUN: the default from 65 536 chunks, BASELINE configs[3]):
-    on a trajectory the neighbouring chunks share their cameras, so the rows of U | g_c written and folded become fewer;
-    with random visibility a chunk alone has more cameras than a run may hold, and every run is one chunk.  U, g_c, V,
-    g_p, W against the numpy restatement (1e-10 of the largest entry), the step against the run-less launch, the rows
-    counted, and the same bits from two set-ups."""
-    import os
-    sc = scenes.ring_scene(120, 6000, 6, visibility=visibility)
-    C, L = 120, 6000
-    a = (sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
-    outs, rows = {}, {}
-    for mode in ("1", "8", "8 again", "3"):
-        os.environ["BA_LIN_RUN"] = mode.split()[0]
-        try:
-            with _native.Solver(linear_solver=2) as s:
-                s.set_problem(C, L, *a)
-                rows[mode] = s.problem_info()["u_rows"]
-                outs[mode] = s.debug_linearization(sc["poses_guess"], sc["points_guess"], 1e-3, want_S=False)
-        finally:
-            del os.environ["BA_LIN_RUN"]
-    r, Jc, Jp = lm.linearize(sc["poses_guess"], sc["points_guess"], *a)
-    free = np.ones(C, bool)
-    free[0] = False
-    Jc = Jc * free[sc["obs_cam"]][:, None, None]
-    U, V, W, gc, gp, _ = lm.normal_blocks(r, Jc, Jp, sc["obs_cam"], sc["obs_pt"], C, L)
-    for mode, out in outs.items():
-        for k, ref in (("U", U), ("V", V), ("W", W), ("gc", gc), ("gp", gp)):
-            np.testing.assert_allclose(out[k], ref, rtol=0, atol=1e-10 * np.abs(ref).max(), err_msg=f"{k} (BA_LIN_RUN={mode})")
-        np.testing.assert_allclose(out["dc"], outs["1"]["dc"], rtol=0, atol=1e-9 * np.abs(outs["1"]["dc"]).max())
-    for k in ("U", "gc", "V", "gp", "dc", "dp"):
-        assert np.array_equal(outs["8"][k], outs["8 again"][k]), k
-    if visibility == "ring":
-        assert rows["8"] < 0.5 * rows["1"] and rows["8"] < rows["3"] < rows["1"], rows
-    else:
-        assert rows["8"] == rows["1"], rows
 
 
 @pytest.mark.parametrize("name", ["noisy_10x300", "ring_50x2000"])

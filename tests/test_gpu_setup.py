@@ -1,11 +1,8 @@
 """ba_set_problem's index tables (the internal observation order, the block pattern of S, the chunk / group / write-out /
-gather tables) are built on host threads since round 3.  tests/golden/table_digests_r02.json holds a digest of every
-table as round 2's single-threaded set-up built it (tools/table_digests.py, commit 9e72c13), tests/golden/
-table_digests.json the same from today's set-up on ONE thread (BA_HOST_THREADS=1).  The threaded set-up must give the
-bits of the second file for every scene there, whatever the number of threads, and every table of round 2 must still be
-among them bit for bit, except the ones that k_linearize_rows' runs of chunks changed on purpose: its group tables
-(lin_gptr, lin_gbeg, lin_gcam, the unused lin_gslot) and the camera -> rows index built from them (ucr_ptr, ucr_row).
-No reference counterpart (the reference's only set-up is the jac_sparsity mask, bundle_adjustment.py:90-154)."""
+gather tables) are built on host threads since round 3.  tests/golden/table_digests.json holds a digest of every table
+as round 2's single-threaded set-up built it (tools/table_digests.py, commit 9e72c13): the threaded set-up must give the
+same bits for every scene there, whatever the number of threads.  No reference counterpart (the reference's only
+set-up is the jac_sparsity mask, bundle_adjustment.py:90-154)."""
 import json
 import os
 import sys
@@ -25,28 +22,13 @@ def recorded():
 
 
 @pytest.fixture(scope="module")
-def recorded_r02():
-    with open(os.path.join(ROOT, "tests", "golden", "table_digests_r02.json")) as fh:
-        return json.load(fh)
-
-
-CHANGED_SINCE_R02 = 6  # lin_gptr, lin_gbeg, lin_gcam, lin_gslot, ucr_ptr, ucr_row
-
-
-def _still_there(got, old):
-    """how many of round 2's tables are missing from today's list (multiset difference)"""
-    from collections import Counter
-    return sum((Counter(old) - Counter(f"{v:016x}" for v in got)).values())
-
-
-@pytest.fixture(scope="module")
 def cases():
     import table_digests
     return table_digests.cases(full=False)
 
 
 @pytest.mark.parametrize("threads", [None, 1, 3, 16])
-def test_tables_are_bit_identical_to_the_single_threaded_setup(recorded, recorded_r02, cases, threads, monkeypatch):
+def test_tables_are_bit_identical_to_the_single_threaded_setup(recorded, cases, threads, monkeypatch):
     import table_digests
     monkeypatch.setenv("BA_TABLE_DIGEST", "1")
     if threads is None:
@@ -56,16 +38,17 @@ def test_tables_are_bit_identical_to_the_single_threaded_setup(recorded, recorde
     for name, case in cases.items():
         got, solver = table_digests.digests(case)
         assert solver == recorded[name]["solver"], name
-        assert [f"{v:016x}" for v in got] == recorded[name]["digests"], (name, threads)
-        # (today's list is longer than round 2's: the runs of k_linearize_rows, and in the batched case the four lists
-        # behind the fixed-order per-window statistics)
-        assert _still_there(got, recorded_r02[name]["digests"]) <= CHANGED_SINCE_R02, name
+        want = recorded[name]["digests"]
+        # (the batched case uploads four tables more than round 2 did: the lists behind the fixed-order per-window
+        # statistics; everything round 2 built must still be there, bit for bit, in the same order)
+        extra = 4 if name == "windows_64x10x100" else 0
+        assert len(got) == len(want) + extra, (name, len(got), len(want))
+        assert [f"{v:016x}" for v in got[: len(want)]] == want, (name, threads)
 
 
-def test_tables_of_config4_and_the_setup_time(recorded, recorded_r02):
-    """BASELINE configs[3] (10 M observations): the same tables as the single-threaded set-up's (and as round 2's, the
-    linearisation's group tables aside), and the set-up inside VERDICT r2's bound (150 ms; it was 650 ms) with some
-    slack for a busy host."""
+def test_tables_of_config4_and_the_setup_time(recorded):
+    """BASELINE configs[3] (10 M observations): the same tables as round 2's, and the set-up inside VERDICT r2's bound
+    (150 ms; it was 650 ms) with some slack for a busy host."""
     import scenes
     from src import _native
     sc = scenes.ring_scene(10000, 2000000, 5)
@@ -77,7 +60,6 @@ def test_tables_of_config4_and_the_setup_time(recorded, recorded_r02):
     finally:
         del os.environ["BA_TABLE_DIGEST"]
     assert [f"{v:016x}" for v in got] == recorded["ring_10000x2000000"]["digests"]
-    assert _still_there(got, recorded_r02["ring_10000x2000000"]["digests"]) <= CHANGED_SINCE_R02
     import time
     best = 1e9
     with _native.Solver() as s:

@@ -1,12 +1,10 @@
 #!/usr/bin/env python3
 """Digests of the tables ba_set_problem builds (ba_debug_table_digests) for a fixed list of scenes.
 
-    BA_HOST_THREADS=1 BA_TABLE_DIGEST=1 python tools/table_digests.py [--full] > tests/golden/table_digests.json
+    BA_TABLE_DIGEST=1 python tools/table_digests.py [--full] > tests/golden/table_digests.json
 
-tests/golden/table_digests_r02.json was written by the single-threaded set-up of round 2 (commit 9e72c13),
-tests/golden/table_digests.json by today's on one thread; tests/test_gpu_setup.py asserts that today's set-up reproduces
-the second whatever BA_HOST_THREADS says, and that all of round 2's tables but the linearisation's group tables are
-still among them."""
+The committed file was written by the single-threaded set-up of round 2 (commit 9e72c13); tests/test_gpu_setup.py asserts
+that today's set-up reproduces every value, whatever BA_HOST_THREADS says."""
 import json
 import os
 import sys

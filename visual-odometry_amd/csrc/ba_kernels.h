@@ -136,17 +136,12 @@ struct DeviceProblem {
   const int* lin_gptr;   // [n_lin_chunks + 1] first entry of each chunk in the group tables (groups + 1 sentinel per chunk)
   const int* lin_gbeg;   // [...] first position of each camera group of a chunk (sentinel: the chunk's free observations)
   const int* lin_gcam;   // [...] the group's camera
-                         // (k_linearize_rows: a chunk's groups are the cameras of its RUN, present in the chunk or not (then
-                         // an empty range): cameras of the run + 1 entries per chunk; lin_gcam = the camera of every row of Urows)
-  const int* lin_run;    // [n_lin_runs + 1] first chunk of each run of k_linearize_rows
-  const int* lin_rowbase;// [n_lin_runs + 1] first row of d.Urows of each run (a row per camera of the run)
-  int n_lin_runs;
   const int* lin_gslot;  // [...] its slot in the workgroup's LDS copy of U | gc, or -1 (straight to the global slab)
   const int* lin_wincam; // [workgroups][LINW_WIN] camera of each slot, -1 = unused
   int n_lin_chunks;      // 0: no chunk tables (some track is longer than LINF_MAXLM)
   // fixed-order accumulation of U | gc and of the scalar statistics (k_linearize_rows, fold_u_rows, k_fold_stats): no
   // atomics, so that two runs of a solve take the same LM path bit for bit
-  double* Urows;         // [3][n_urows][9] U | gc summed per (run of chunks, camera of the run): row = index into lin_gcam
+  double* Urows;         // [3][n_urows][9] U | gc summed per (chunk, camera group of the chunk): row = index into lin_gcam
   long n_urows;          // entries of the group tables (one sentinel per chunk included); 0: the atomics kernels linearise
   const int* ucr_ptr;    // [C * nslab_u + 1] rows of camera c, cut into nslab_u segments: segment s is ucr_row[ucr_ptr[c * nslab_u + s] .. [+ 1])
   const int* ucr_row;    // [...] ascending
@@ -383,14 +378,6 @@ constexpr int LINF_MAXC = 64;     // cameras: the per-workgroup copy of U | gc c
 constexpr int LINF_MAXLM = 32;    // landmarks per chunk == longest track
 constexpr int LINF_VSTRIDE = 11;  // 9 values per observation + pad (odd: conflict-free column access)
 constexpr int LINF_WAVES = 4;     // waves per workgroup
-// k_linearize_rows: a wave takes a RUN of up to LINR_MAXRUN consecutive chunks whose cameras together number at most
-// LINR_MAXG (LINR_ITEMS (camera, entry) sums per lane and plane, in registers), or a single chunk with any number of
-// cameras; the host cuts the runs inside fixed blocks of LINR_BLOCK chunks (so that the tables do not depend on the
-// number of host threads that build them)
-constexpr int LINR_ITEMS = 3;
-constexpr int LINR_MAXG = LINR_ITEMS * 64 / 9;  // 21
-constexpr int LINR_MAXRUN = 8;
-constexpr int LINR_BLOCK = 4096;
 
 template <bool ROBUST>
 __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_flat(DeviceProblem d, const double* __restrict__ poses,
@@ -744,7 +731,7 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_w
 // A wave touches nobody else's data: no workgroup barrier at all (the LDS serves one wave's accesses in order).
 // Algorithmic bytes: those of k_linearize_win + 216 B per (chunk, camera) row written.
 template <bool ROBUST>
-__global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_rows(DeviceProblem d, const double* __restrict__ poses,
+__global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 6) void k_linearize_rows(DeviceProblem d, const double* __restrict__ poses,
                                                                        const double* __restrict__ pts) {
   __shared__ double sVg[LINF_WAVES][64 * LINF_VSTRIDE];
   __shared__ double sP[LINF_WAVES][LINF_MAXLM * 3];
@@ -756,21 +743,10 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_r
     pts = d.pts_buf[c->sel];
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int run = __builtin_amdgcn_readfirstlane(blockIdx.x * LINF_WAVES + wave);
-  if (run >= d.n_lin_runs) return;  // (no workgroup barrier below)
-  const int c0 = d.lin_run[run], c1 = d.lin_run[run + 1];
-  const int rowb = d.lin_rowbase[run], ng = d.lin_rowbase[run + 1] - rowb;  // the run's rows = its cameras
-  const bool in_regs = ng <= LINR_MAXG;  // (a run of several chunks always is)
-  double acc[3][LINR_ITEMS];
-#pragma unroll
-  for (int ph = 0; ph < 3; ++ph)
-#pragma unroll
-    for (int j = 0; j < LINR_ITEMS; ++j) acc[ph][j] = 0.0;
-  double* const myP = sP[wave];
-  double* const myV = sVg[wave];
-  for (int c = c0; c < c1; ++c) {
+  const int c = __builtin_amdgcn_readfirstlane(blockIdx.x * LINF_WAVES + wave);
+  if (c >= d.n_lin_chunks) return;  // (no workgroup barrier below)
   const int jb = d.lin_lm[c], je = d.lin_lm[c + 1], kb = d.lin_k[c], ke = d.lin_k[c + 1];
-  const int gb = d.lin_gptr[c];  // ng + 1 entries: where each of the run's cameras starts in this chunk's rows
+  const int gb = d.lin_gptr[c], ng = d.lin_gptr[c + 1] - gb - 1;
   const int k = kb + lane;
   const bool act = k < ke;
   int cam = 0, fr = -1, lm = jb, tb = 0, te = 0, pos = lane;  // pos: this observation's row in camera order
@@ -791,6 +767,8 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_r
 #pragma unroll
     for (int i = 0; i < 7; ++i) pose[i] = poses[7 * cam + i];
   }
+  double* myP = sP[wave];
+  double* myV = sVg[wave];
   if (lm_lane) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) myP[3 * lane + i] = Pl[i];
@@ -884,9 +862,10 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_r
       if (e >= 9 * ph && e < 9 * ph + 9) myV[pos * LINF_VSTRIDE + e - 9 * ph] = Jc[i] * r[0] + Jc[6 + i] * r[1];
     }
     __builtin_amdgcn_wave_barrier();
-    // the rows of a camera are consecutive: four independent LDS reads in flight; fixed order
-    auto camera_sum = [&](int item) {
+    double* __restrict__ plane = d.Urows + ((long)ph * d.n_urows + gb) * 9;
+    for (int item = lane; item < ng * 9; item += 64) {
       const int g = item / 9, q = item - 9 * g;
+      // the rows of a camera are consecutive: four independent LDS reads in flight; fixed order
       const int p1 = sGbeg[wave][g + 1];
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
       for (int p = sGbeg[wave][g]; p < p1; p += 4) {
@@ -895,32 +874,13 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_r
                      a3 = p + 3 < p1 ? row[3 * LINF_VSTRIDE] : 0.0;
         s0 += a0; s1 += a1; s2 += a2; s3 += a3;
       }
-      return (s0 + s1) + (s2 + s3);
-    };
-    if (in_regs) {  // chunk after chunk of the run into the lane's registers (ascending chunks: a fixed order)
-#pragma unroll
-      for (int j = 0; j < LINR_ITEMS; ++j)
-        if (lane + 64 * j < ng * 9) acc[ph][j] += camera_sum(lane + 64 * j);
-    } else {  // a single chunk with many cameras: straight out
-      double* __restrict__ plane = d.Urows + ((long)ph * d.n_urows + rowb) * 9;
-      for (int item = lane; item < ng * 9; item += 64) plane[item] = camera_sum(item);
+      plane[item] = (s0 + s1) + (s2 + s3);
     }
   }
   cost = wave_sum_dpp(cost);
   gmax = group_max<64>(gmax);
   const double bb = (double)__popcll(__ballot(nbehind != 0)), bz = (double)__popcll(__ballot(nzero != 0));  // (0 or 1 per lane)
   if (lane < 4) d.lin_part[4L * c + lane] = lane == 0 ? cost : lane == 1 ? bb : lane == 2 ? bz : gmax;
-  __builtin_amdgcn_wave_barrier();  // the next chunk reuses the wave's LDS
-  }
-  if (in_regs) {
-#pragma unroll
-    for (int ph = 0; ph < 3; ++ph) {
-      double* __restrict__ plane = d.Urows + ((long)ph * d.n_urows + rowb) * 9;
-#pragma unroll
-      for (int j = 0; j < LINR_ITEMS; ++j)
-        if (lane + 64 * j < ng * 9) plane[lane + 64 * j] = acc[ph][j];
-    }
-  }
 }
 
 // fold_u_rows: segment `s` of camera `cam`: the sum of the rows of d.Urows that the inverted index lists for it, in

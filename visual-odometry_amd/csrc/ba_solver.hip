@@ -18,7 +18,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <iterator>
 #include <numeric>
 #include <memory>
 #include <string>
@@ -487,7 +486,7 @@ inline size_t linf_lds_bytes(int C) {
 void launch_linearize(ba_handle* h, const double* poses, const double* pts) {
   const DeviceProblem& d = h->d;
   if (h->lin_rows) {
-    const int grid = grid_for(d.n_lin_runs, LINF_WAVES);
+    const int grid = grid_for(d.n_lin_chunks, LINF_WAVES);
     if (d.loss.kind == LOSS_LINEAR) launch_timed(h, KT_LIN, k_linearize_rows<false>, grid, 64 * LINF_WAVES, d, poses, pts);
     else launch_timed(h, KT_LIN, k_linearize_rows<true>, grid, 64 * LINF_WAVES, d, poses, pts);
     return;
@@ -1733,71 +1732,7 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
       for (int e : pc.gend) lin_gptr.push_back(base + e);
     }
   }
-  std::vector<int> lin_run(1, 0), lin_rowbase(1, 0);
   if (h->lin_rows) {
-    // Runs of k_linearize_rows: a wave takes up to `rmax` consecutive chunks and sums U | gc of the cameras they share
-    // in registers, one row of d.Urows per (run, camera) instead of one per (chunk, camera): landmarks are ordered by
-    // the cameras that see them, so neighbouring chunks mostly share theirs (BASELINE configs[3]: 3.2 times fewer rows
-    // to write and to fold).  Only when the launch keeps the chip busy without it (rmax grows with the chunk count).
-    // The group tables become: per chunk, where each camera OF THE RUN starts among the chunk's rows.
-    const int chunks = h->flat_chunks;
-    const int rmax = std::max(1, std::min(LINR_MAXRUN, env_int("BA_LIN_RUN", (int)std::min<long>(LINR_MAXRUN, chunks / 8192))));
-    const int nblk = (chunks + LINR_BLOCK - 1) / LINR_BLOCK;
-    struct RunPiece { std::vector<int> first, row_end, cam, gend, gbeg; };
-    std::vector<RunPiece> rp((size_t)nblk);
-    hostpar::run(std::min(hostpar::threads_for(n, 16384), std::max(nblk, 1)), [&](int t, int nt) {
-      std::vector<int> uni, nxt;
-      for (int b = t; b < nblk; b += nt) {
-        RunPiece& pc = rp[(size_t)b];
-        const int cb = b * LINR_BLOCK, ce = std::min(chunks, cb + LINR_BLOCK);
-        for (int c = cb; c < ce;) {
-          uni.assign(lin_gcam.begin() + lin_gptr[c], lin_gcam.begin() + lin_gptr[c + 1] - 1);
-          int c1 = c + 1;
-          while (c1 < ce && c1 - c < rmax && (int)uni.size() <= LINR_MAXG) {
-            nxt.clear();
-            std::set_union(uni.begin(), uni.end(), lin_gcam.begin() + lin_gptr[c1], lin_gcam.begin() + lin_gptr[c1 + 1] - 1,
-                           std::back_inserter(nxt));
-            if ((int)nxt.size() > LINR_MAXG) break;
-            uni.swap(nxt);
-            ++c1;
-          }
-          pc.first.push_back(c);
-          pc.cam.insert(pc.cam.end(), uni.begin(), uni.end());
-          pc.row_end.push_back((int)pc.cam.size());
-          for (int cc = c; cc < c1; ++cc) {
-            const int g0 = lin_gptr[cc], ngc = lin_gptr[cc + 1] - g0 - 1;
-            int g = 0;  // cameras of the chunk below the run's current one
-            for (int cam : uni) {
-              pc.gbeg.push_back(lin_gbeg[g0 + g]);  // (g == ngc: the sentinel, the chunk's free observations)
-              if (g < ngc && lin_gcam[g0 + g] == cam) ++g;
-            }
-            pc.gbeg.push_back(lin_gbeg[g0 + ngc]);
-            pc.gend.push_back((int)pc.gbeg.size());
-          }
-          c = c1;
-        }
-      }
-    });
-    size_t tot_g = 0, tot_r = 0, tot_run = 0;
-    for (const RunPiece& pc : rp) { tot_g += pc.gbeg.size(); tot_r += pc.cam.size(); tot_run += pc.first.size(); }
-    std::vector<int> gptr2(1, 0), gbeg2, row_cam;
-    gptr2.reserve((size_t)chunks + 1); gbeg2.reserve(tot_g); row_cam.reserve(tot_r);
-    lin_run.clear(); lin_rowbase.clear();
-    lin_run.reserve(tot_run + 1); lin_rowbase.reserve(tot_run + 1);
-    for (const RunPiece& pc : rp) {
-      const int gbase = (int)gbeg2.size(), rbase = (int)row_cam.size();
-      for (size_t i = 0; i < pc.first.size(); ++i) {
-        lin_run.push_back(pc.first[i]);
-        lin_rowbase.push_back(rbase + (i ? pc.row_end[i - 1] : 0));
-      }
-      for (int e : pc.gend) gptr2.push_back(gbase + e);
-      gbeg2.insert(gbeg2.end(), pc.gbeg.begin(), pc.gbeg.end());
-      row_cam.insert(row_cam.end(), pc.cam.begin(), pc.cam.end());
-    }
-    lin_run.push_back(chunks);
-    lin_rowbase.push_back((int)row_cam.size());
-    lin_gptr.swap(gptr2); lin_gbeg.swap(gbeg2); lin_gcam.swap(row_cam);
-    std::vector<int>().swap(lin_gslot);
     // inverted index camera -> rows of d.Urows (= entries of the group tables), ascending, cut into `rows_nslab` segments
     // per camera: a wave of the fold sums one segment (fold_u_rows), the gather sums the segments
     std::vector<int> per_cam(C + 1, 0);
@@ -2398,8 +2333,6 @@ int set_problem_impl(ba_handle* h, int32_t C, int32_t L, int32_t n, const int32_
   queue_upload(h, &d.lin_perm, lin_perm); queue_upload(h, &d.lin_gptr, lin_gptr);
   queue_upload(h, &d.lin_gbeg, lin_gbeg); queue_upload(h, &d.lin_gcam, lin_gcam);
   queue_upload(h, &d.lin_gslot, lin_gslot); queue_upload(h, &d.lin_wincam, lin_wincam);
-  queue_upload(h, &d.lin_run, lin_run); queue_upload(h, &d.lin_rowbase, lin_rowbase);
-  d.n_lin_runs = h->lin_rows ? (int)lin_run.size() - 1 : 0;
   queue_upload(h, &d.ucr_ptr, ucr_ptr); queue_upload(h, &d.ucr_row, ucr_row);
   queue_upload(h, &d.sch_lm, sch_lm); queue_upload(h, &d.sch_k, sch_k);
   queue_upload(h, &d.sch_flush, sch_flush); queue_upload(h, &d.sch_blk_row, sch_blk_row);
