@@ -829,22 +829,35 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 6) void k_linearize_r
   for (int i = 0; i < 9; ++i) myV[lane * LINF_VSTRIDE + i] = vg[i];
   myV[lane * LINF_VSTRIDE + 9] = zc;
   __builtin_amdgcn_wave_barrier();
-  if (lm_lane) {
-    const int jl = jb + lane;
-    double s9[9], zmn = 1e300;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) s9[i] = 0.0;
-    for (int t = tb; t < te; ++t) {
-#pragma unroll
-      for (int i = 0; i < 9; ++i) s9[i] += myV[t * LINF_VSTRIDE + i];
-      zmn = fmin(zmn, myV[t * LINF_VSTRIDE + 9]);
+  // a lane per (track, entry) for the nine sums of a track (V 6, gp 3), the track's rows added in their order (the same
+  // sums, bit for bit, as one lane per track made; with a dozen tracks per chunk that left four lanes in five idle and
+  // cost half of the kernel's LDS instructions); the smallest depth of a track stays with the track's lane
+  {
+    const int n_items = (je - jb) * 9;
+    for (int base = 0; base < n_items; base += 64) {  // (uniform: every lane takes part in the shuffles)
+      const int item = base + lane;
+      const bool on = item < n_items;
+      const int t = on ? item / 9 : 0, i = item - 9 * t;
+      const int p0 = __shfl(tb, t), p1 = __shfl(te, t);
+      if (on) {
+        double a = 0.0;
+        int p = p0;
+        const double* row = myV + p0 * LINF_VSTRIDE + i;
+        for (; p + 4 <= p1; p += 4, row += 4 * LINF_VSTRIDE) {  // four LDS reads in flight, added one after the other
+          const double x0 = row[0], x1 = row[LINF_VSTRIDE], x2 = row[2 * LINF_VSTRIDE], x3 = row[3 * LINF_VSTRIDE];
+          a = (((a + x0) + x1) + x2) + x3;
+        }
+        for (; p < p1; ++p, row += LINF_VSTRIDE) a += row[0];
+        const int jl = jb + t;
+        if (i < 6) d.V[(long)i * d.L + jl] = a;
+        else { d.gp[(long)(i - 6) * d.L + jl] = a; gmax = fmax(gmax, fabs(a)); }
+      }
     }
-    d.zmin[jl] = zmn;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) d.V[(long)i * d.L + jl] = s9[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) d.gp[(long)i * d.L + jl] = s9[6 + i];
-    gmax = fmax(fabs(s9[6]), fmax(fabs(s9[7]), fabs(s9[8])));
+    if (lm_lane) {
+      double zmn = 1e300;
+      for (int t = tb; t < te; ++t) zmn = fmin(zmn, myV[t * LINF_VSTRIDE + 9]);
+      d.zmin[jb + lane] = zmn;
+    }
   }
   // U | gc: 27 values per observation, nine at a time through the same rows; the sum of a camera group goes out as
   // nine consecutive doubles of plane ph of d.Urows (a wave's stores of a phase are contiguous: ng * 9 doubles)
