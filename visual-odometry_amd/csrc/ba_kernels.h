@@ -731,11 +731,12 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_w
 // A wave touches nobody else's data: no workgroup barrier at all (the LDS serves one wave's accesses in order).
 // Algorithmic bytes: those of k_linearize_win + 216 B per (chunk, camera) row written.
 template <bool ROBUST>
-__global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 6) void k_linearize_rows(DeviceProblem d, const double* __restrict__ poses,
+__global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 7) void k_linearize_rows(DeviceProblem d, const double* __restrict__ poses,
                                                                        const double* __restrict__ pts) {
+  // 22.8 KB of LDS and at most 72 VGPRs: seven workgroups per CU (the landmark positions travel by shuffles, not through
+  // a table in LDS, and the group table holds bytes: with both as before a CU took six)
   __shared__ double sVg[LINF_WAVES][64 * LINF_VSTRIDE];
-  __shared__ double sP[LINF_WAVES][LINF_MAXLM * 3];
-  __shared__ int sGbeg[LINF_WAVES][65];
+  __shared__ unsigned char sGbeg[LINF_WAVES][68];
   if (poses == nullptr) {  // solver mode
     const LmCtrl* c = d.ctrl;
     if (c->done || !c->need_lin) return;
@@ -747,55 +748,46 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 6) void k_linearize_r
   if (c >= d.n_lin_chunks) return;  // (no workgroup barrier below)
   const int jb = d.lin_lm[c], je = d.lin_lm[c + 1], kb = d.lin_k[c], ke = d.lin_k[c + 1];
   const int gb = d.lin_gptr[c], ng = d.lin_gptr[c + 1] - gb - 1;
-  const int k = kb + lane;
-  const bool act = k < ke;
-  int cam = 0, fr = -1, lm = jb, tb = 0, te = 0, pos = lane;  // pos: this observation's row in camera order
-  double u = 0.0, v = 0.0, Pl[3] = {0.0, 0.0, 1.0};
-  if (act) {
-    cam = d.o_cam[k]; fr = d.o_free[k]; lm = d.o_lm[k]; u = d.o_u[k]; v = d.o_v[k];
-    pos = d.lin_perm[k];
-  }
-  if (lane <= ng) sGbeg[wave][lane] = d.lin_gbeg[gb + lane];  // (entry ng: the sentinel = the chunk's free observations)
+  // the lanes beyond the chunk's observations repeat its last one (no branch around the arithmetic, no defaults to
+  // set up for it): they park their products in rows of their own that nobody sums, and store nothing
+  const bool act = kb + lane < ke;
+  const int k = act ? kb + lane : ke - 1;
+  int tb = 0, te = 0;
+  double Pl[3] = {0.0, 0.0, 1.0};
+  const int cam = d.o_cam[k], fr = d.o_free[k], lm = d.o_lm[k];
+  const double u = d.o_u[k], v = d.o_v[k];
+  const int pos = act ? (int)d.lin_perm[k] : lane;  // this observation's row in camera order
+  if (lane <= ng) sGbeg[wave][lane] = (unsigned char)d.lin_gbeg[gb + lane];  // (entry ng: the sentinel = the chunk's free observations, <= 64)
   const bool lm_lane = lane < je - jb;
   if (lm_lane) {
     tb = d.lm_ptr[jb + lane] - kb; te = d.lm_ptr[jb + lane + 1] - kb;
 #pragma unroll
     for (int i = 0; i < 3; ++i) Pl[i] = pts[3 * (long)(jb + lane) + i];
   }
-  double pose[7] = {0, 0, 0, 1, 0, 0, 0};
-  if (act) {
+  double pose[7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) pose[i] = poses[7 * cam + i];
-  }
-  double* myP = sP[wave];
+  for (int i = 0; i < 7; ++i) pose[i] = poses[7 * cam + i];
   double* myV = sVg[wave];
-  if (lm_lane) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) myP[3 * lane + i] = Pl[i];
-  }
-  __builtin_amdgcn_wave_barrier();  // myP, the group table
+  __builtin_amdgcn_wave_barrier();  // the group table
   const bool is_free = act && fr >= 0;
   double cost = 0.0, gmax = 0.0;
   int nbehind = 0, nzero = 0;
-  double vg[9], Jc[12], r[2] = {0.0, 0.0};
-#pragma unroll
-  for (int i = 0; i < 9; ++i) vg[i] = 0.0;
-#pragma unroll
-  for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
-  double zc = 1e300;
-  if (act) {
-    const double P[3] = {myP[3 * (lm - jb)], myP[3 * (lm - jb) + 1], myP[3 * (lm - jb) + 2]};
+  double vg[9], Jc[12], r[2];
+  double zc;
+  {
+    const double P[3] = {__shfl(Pl[0], lm - jb), __shfl(Pl[1], lm - jb), __shfl(Pl[2], lm - jb)};  // from the landmark's lane
     double Jp[6];
     linearize_obs(d.K, pose, P, u, v, r, Jc, Jp, zc);
-    nbehind += (zc <= 0.0);
-    nzero += (zc == 0.0);
+    nbehind += (act && zc <= 0.0);
+    nzero += (act && zc == 0.0);
     if (!ROBUST) {
-      cost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
+      cost = act ? 0.5 * (r[0] * r[0] + r[1] * r[1]) : 0.0;
     } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         double sc;
-        cost += robust_scale(d.loss, r[i], sc);
+        const double rho_i = robust_scale(d.loss, r[i], sc);
+        cost += act ? rho_i : 0.0;
 #pragma unroll
         for (int q = 0; q < 6; ++q) Jc[6 * i + q] *= sc;
 #pragma unroll
@@ -815,7 +807,7 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 6) void k_linearize_r
 #pragma unroll
       for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
     }
-    if (d.W) {  // (no buffer: the consumers rebuild W themselves)
+    if (d.W && act) {  // (no buffer: the consumers rebuild W themselves)
       double* __restrict__ Wk = d.W + k;
       const long n = d.n;
       double jw[W_ROWS];
@@ -881,11 +873,16 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 6) void k_linearize_r
       // the rows of a camera are consecutive: four independent LDS reads in flight; fixed order
       const int p1 = sGbeg[wave][g + 1];
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      for (int p = sGbeg[wave][g]; p < p1; p += 4) {
-        const double* row = myV + p * LINF_VSTRIDE + q;
-        const double a0 = row[0], a1 = p + 1 < p1 ? row[LINF_VSTRIDE] : 0.0, a2 = p + 2 < p1 ? row[2 * LINF_VSTRIDE] : 0.0,
-                     a3 = p + 3 < p1 ? row[3 * LINF_VSTRIDE] : 0.0;
+      int p = sGbeg[wave][g];
+      const double* row = myV + p * LINF_VSTRIDE + q;
+      for (; p + 4 <= p1; p += 4, row += 4 * LINF_VSTRIDE) {  // whole steps without the tail's tests
+        const double a0 = row[0], a1 = row[LINF_VSTRIDE], a2 = row[2 * LINF_VSTRIDE], a3 = row[3 * LINF_VSTRIDE];
         s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+      }
+      if (p < p1) {  // the last one to three rows, into the accumulators they would have met in a padded step
+        s0 += row[0];
+        if (p + 1 < p1) s1 += row[LINF_VSTRIDE];
+        if (p + 2 < p1) s2 += row[2 * LINF_VSTRIDE];
       }
       plane[item] = (s0 + s1) + (s2 + s3);
     }
