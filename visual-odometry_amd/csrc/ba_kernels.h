@@ -2789,8 +2789,8 @@ __device__ __forceinline__ void comp_store(const CompLm& q, int chunk, int slot,
   }
 }
 
-template <bool ROBUST>
-__global__ __launch_bounds__(256) void k_backsub_flat(DeviceProblem d, double lam, double min_diag,
+template <bool ROBUST, bool MF>
+__global__ __launch_bounds__(256, MF ? 4 : 5) void k_backsub_flat(DeviceProblem d, double lam, double min_diag,
                                                       const double* __restrict__ pts, double* __restrict__ pts_t,
                                                       const double* __restrict__ poses, double* __restrict__ poses_t,
                                                       int pose_blocks, int guard, int with_cost) {
@@ -2822,7 +2822,7 @@ __global__ __launch_bounds__(256) void k_backsub_flat(DeviceProblem d, double la
   const int k = kb + lane;
   const bool act = k < ke;
   // round 1: everything whose address is known from the chunk bounds
-  const bool mf = d.W == nullptr;  // matrix free: W is rebuilt from the record, the pose and the point (no stored factors)
+  constexpr bool mf = MF;  // matrix free (d.W == nullptr): W is rebuilt from the record, the pose and the point (no stored factors)
   int f = -1, cam = 0, lm = jb;
   double jw[W_ROWS], u = 0.0, v = 0.0;
 #pragma unroll
@@ -2858,7 +2858,7 @@ __global__ __launch_bounds__(256) void k_backsub_flat(DeviceProblem d, double la
 #pragma unroll
     for (int i = 0; i < 6; ++i) dl[i] = d.dc[6 * f + i];
   }
-  if (act && (with_cost || mf)) {
+  if (mf && act) {  // (stored W: the pose is only needed for the trial cost, and is fetched there: 14 registers less across the middle)
 #pragma unroll
     for (int i = 0; i < 7; ++i) ps[i] = poses[7 * cam + i];
   }
@@ -2936,6 +2936,10 @@ __global__ __launch_bounds__(256) void k_backsub_flat(DeviceProblem d, double la
   double cost = 0.0;
   int nbehind = 0, nzero = 0;
   if (with_cost) {
+    if (!mf && act) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i) ps[i] = poses[7 * cam + i];
+    }
     __syncthreads();
     if (act) {
       const int li = lm - jb;

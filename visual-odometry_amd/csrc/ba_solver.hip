@@ -533,9 +533,11 @@ bool launch_backsub(ba_handle* h, double lam, const double* pts, double* pts_t, 
     const int grid = grid_for(h->flat_chunks, 4) + pb;
     const int with_cost = lam < 0.0;
     if (d.loss.kind == LOSS_LINEAR)
-      launch_timed(h, KT_BACKSUB, k_backsub_flat<false>, grid, 256, d, lam, h->opt.min_diag, pts, pts_t, poses, poses_t, pb, 0, with_cost);
+      if (d.W) launch_timed(h, KT_BACKSUB, k_backsub_flat<false, false>, grid, 256, d, lam, h->opt.min_diag, pts, pts_t, poses, poses_t, pb, 0, with_cost);
+      else launch_timed(h, KT_BACKSUB, k_backsub_flat<false, true>, grid, 256, d, lam, h->opt.min_diag, pts, pts_t, poses, poses_t, pb, 0, with_cost);
     else
-      launch_timed(h, KT_BACKSUB, k_backsub_flat<true>, grid, 256, d, lam, h->opt.min_diag, pts, pts_t, poses, poses_t, pb, 0, with_cost);
+      if (d.W) launch_timed(h, KT_BACKSUB, k_backsub_flat<true, false>, grid, 256, d, lam, h->opt.min_diag, pts, pts_t, poses, poses_t, pb, 0, with_cost);
+      else launch_timed(h, KT_BACKSUB, k_backsub_flat<true, true>, grid, 256, d, lam, h->opt.min_diag, pts, pts_t, poses, poses_t, pb, 0, with_cost);
     return with_cost != 0;
   }
   const int G = h->g_lin, lpg = h->lpg_back;
