@@ -378,6 +378,10 @@ constexpr int LINF_MAXC = 64;     // cameras: the per-workgroup copy of U | gc c
 constexpr int LINF_MAXLM = 32;    // landmarks per chunk == longest track
 constexpr int LINF_VSTRIDE = 11;  // 9 values per observation + pad (odd: conflict-free column access)
 constexpr int LINF_WAVES = 4;     // waves per workgroup
+constexpr int LINR_VSTRIDE = 9;   // k_linearize_rows: nine values per row, no pad.  ds_read_b64 banks by (address / 4) mod 64 in two
+                                  // halves of 32 lanes: the lanes (camera, entry) of the camera sums read nine consecutive doubles per
+                                  // camera, windows that collide least when rows are dense (simulated for typical chunks and measured:
+                                  // stride 11 cost 60-72 LDS cycles per phase where 9 costs 30-42 and the ideal is 18-27)
 
 template <bool ROBUST>
 __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_flat(DeviceProblem d, const double* __restrict__ poses,
@@ -733,9 +737,10 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 4) void k_linearize_w
 template <bool ROBUST>
 __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 7) void k_linearize_rows(DeviceProblem d, const double* __restrict__ poses,
                                                                        const double* __restrict__ pts) {
-  // 22.8 KB of LDS and at most 72 VGPRs: seven workgroups per CU (the landmark positions travel by shuffles, not through
+  // 20.8 KB of LDS and at most 72 VGPRs: seven workgroups per CU (the landmark positions travel by shuffles, not through
   // a table in LDS, and the group table holds bytes: with both as before a CU took six)
-  __shared__ double sVg[LINF_WAVES][64 * LINF_VSTRIDE];
+  __shared__ double sVg[LINF_WAVES][64 * LINR_VSTRIDE];
+  __shared__ double sZc[LINF_WAVES][64];  // the depth of every observation (the rows hold nine values: V | gp, then U | gc nine at a time)
   __shared__ unsigned char sGbeg[LINF_WAVES][68];
   if (poses == nullptr) {  // solver mode
     const LmCtrl* c = d.ctrl;
@@ -818,8 +823,8 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 7) void k_linearize_r
   }
   // V, gp of the chunk's landmarks: rows parked per observation, summed per track in track order
 #pragma unroll
-  for (int i = 0; i < 9; ++i) myV[lane * LINF_VSTRIDE + i] = vg[i];
-  myV[lane * LINF_VSTRIDE + 9] = zc;
+  for (int i = 0; i < 9; ++i) myV[lane * LINR_VSTRIDE + i] = vg[i];
+  sZc[wave][lane] = zc;
   __builtin_amdgcn_wave_barrier();
   // a lane per (track, entry) for the nine sums of a track (V 6, gp 3), the track's rows added in their order (the same
   // sums, bit for bit, as one lane per track made; with a dozen tracks per chunk that left four lanes in five idle and
@@ -834,12 +839,12 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 7) void k_linearize_r
       if (on) {
         double a = 0.0;
         int p = p0;
-        const double* row = myV + p0 * LINF_VSTRIDE + i;
-        for (; p + 4 <= p1; p += 4, row += 4 * LINF_VSTRIDE) {  // four LDS reads in flight, added one after the other
-          const double x0 = row[0], x1 = row[LINF_VSTRIDE], x2 = row[2 * LINF_VSTRIDE], x3 = row[3 * LINF_VSTRIDE];
+        const double* row = myV + p0 * LINR_VSTRIDE + i;
+        for (; p + 4 <= p1; p += 4, row += 4 * LINR_VSTRIDE) {  // four LDS reads in flight, added one after the other
+          const double x0 = row[0], x1 = row[LINR_VSTRIDE], x2 = row[2 * LINR_VSTRIDE], x3 = row[3 * LINR_VSTRIDE];
           a = (((a + x0) + x1) + x2) + x3;
         }
-        for (; p < p1; ++p, row += LINF_VSTRIDE) a += row[0];
+        for (; p < p1; ++p, row += LINR_VSTRIDE) a += row[0];
         const int jl = jb + t;
         if (i < 6) d.V[(long)i * d.L + jl] = a;
         else { d.gp[(long)(i - 6) * d.L + jl] = a; gmax = fmax(gmax, fabs(a)); }
@@ -847,7 +852,7 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 7) void k_linearize_r
     }
     if (lm_lane) {
       double zmn = 1e300;
-      for (int t = tb; t < te; ++t) zmn = fmin(zmn, myV[t * LINF_VSTRIDE + 9]);
+      for (int t = tb; t < te; ++t) zmn = fmin(zmn, sZc[wave][t]);
       d.zmin[jb + lane] = zmn;
     }
   }
@@ -861,10 +866,10 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 7) void k_linearize_r
 #pragma unroll
       for (int q = i; q < 6; ++q) {
         const int e = sym6_index(i, q);
-        if (e >= 9 * ph && e < 9 * ph + 9) myV[pos * LINF_VSTRIDE + e - 9 * ph] = Jc[i] * Jc[q] + Jc[6 + i] * Jc[6 + q];
+        if (e >= 9 * ph && e < 9 * ph + 9) myV[pos * LINR_VSTRIDE + e - 9 * ph] = Jc[i] * Jc[q] + Jc[6 + i] * Jc[6 + q];
       }
       const int e = 21 + i;
-      if (e >= 9 * ph && e < 9 * ph + 9) myV[pos * LINF_VSTRIDE + e - 9 * ph] = Jc[i] * r[0] + Jc[6 + i] * r[1];
+      if (e >= 9 * ph && e < 9 * ph + 9) myV[pos * LINR_VSTRIDE + e - 9 * ph] = Jc[i] * r[0] + Jc[6 + i] * r[1];
     }
     __builtin_amdgcn_wave_barrier();
     double* __restrict__ plane = d.Urows + ((long)ph * d.n_urows + gb) * 9;
@@ -874,15 +879,15 @@ __global__ __launch_bounds__(64 * LINF_WAVES, ROBUST ? 2 : 7) void k_linearize_r
       const int p1 = sGbeg[wave][g + 1];
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
       int p = sGbeg[wave][g];
-      const double* row = myV + p * LINF_VSTRIDE + q;
-      for (; p + 4 <= p1; p += 4, row += 4 * LINF_VSTRIDE) {  // whole steps without the tail's tests
-        const double a0 = row[0], a1 = row[LINF_VSTRIDE], a2 = row[2 * LINF_VSTRIDE], a3 = row[3 * LINF_VSTRIDE];
+      const double* row = myV + p * LINR_VSTRIDE + q;
+      for (; p + 4 <= p1; p += 4, row += 4 * LINR_VSTRIDE) {  // whole steps without the tail's tests
+        const double a0 = row[0], a1 = row[LINR_VSTRIDE], a2 = row[2 * LINR_VSTRIDE], a3 = row[3 * LINR_VSTRIDE];
         s0 += a0; s1 += a1; s2 += a2; s3 += a3;
       }
       if (p < p1) {  // the last one to three rows, into the accumulators they would have met in a padded step
         s0 += row[0];
-        if (p + 1 < p1) s1 += row[LINF_VSTRIDE];
-        if (p + 2 < p1) s2 += row[2 * LINF_VSTRIDE];
+        if (p + 1 < p1) s1 += row[LINR_VSTRIDE];
+        if (p + 2 < p1) s2 += row[2 * LINR_VSTRIDE];
       }
       plane[item] = (s0 + s1) + (s2 + s3);
     }
