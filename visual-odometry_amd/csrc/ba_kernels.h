@@ -2824,23 +2824,20 @@ __global__ __launch_bounds__(256, MF ? 4 : 5) void k_backsub_flat(DeviceProblem 
   int kb = 0, ke = 0, jb = 0, je = 0;
   if (have) { jb = d.lin_lm[c]; je = d.lin_lm[c + 1]; kb = d.lin_k[c]; ke = d.lin_k[c + 1]; }
   const long n = d.n;
-  const int k = kb + lane;
-  const bool act = k < ke;
+  // the lanes beyond the chunk's observations repeat its last one (as in k_linearize_rows: no branch around the
+  // arithmetic, no defaults to merge): their rows of the exchange are read by nobody, their cost is not counted
+  const bool act = kb + lane < ke;
+  const int k = have ? (act ? kb + lane : ke - 1) : 0;
   // round 1: everything whose address is known from the chunk bounds
   constexpr bool mf = MF;  // matrix free (d.W == nullptr): W is rebuilt from the record, the pose and the point (no stored factors)
-  int f = -1, cam = 0, lm = jb;
+  int cam = 0;
   double jw[W_ROWS], u = 0.0, v = 0.0;
+  const int f = d.o_free[k], lm = d.o_lm[k];
+  if (!mf) {
 #pragma unroll
-  for (int i = 0; i < W_ROWS; ++i) jw[i] = 0.0;
-  if (act) {
-    f = d.o_free[k];
-    lm = d.o_lm[k];
-    if (!mf) {
-#pragma unroll
-      for (int i = 0; i < W_ROWS; ++i) jw[i] = d.W[(long)i * n + k];
-    }
-    if (with_cost || mf) { cam = d.o_cam[k]; u = d.o_u[k]; v = d.o_v[k]; }
+    for (int i = 0; i < W_ROWS; ++i) jw[i] = d.W[(long)i * n + k];
   }
+  if (with_cost || mf) { cam = d.o_cam[k]; u = d.o_u[k]; v = d.o_v[k]; }
   const bool lm_lane = lane < je - jb;
   const long j = jb + lane;
   int tb = 0, te = 0;
@@ -2859,11 +2856,11 @@ __global__ __launch_bounds__(256, MF ? 4 : 5) void k_backsub_flat(DeviceProblem 
   }
   // round 2: the camera step of this observation (and, for the trial cost, its pose)
   double dl[6] = {0, 0, 0, 0, 0, 0}, ps[7] = {0, 0, 0, 1, 0, 0, 0};
-  if (act && f >= 0) {
+  if (f >= 0) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) dl[i] = d.dc[6 * f + i];
   }
-  if (mf && act) {  // (stored W: the pose is only needed for the trial cost, and is fetched there: 14 registers less across the middle)
+  if (mf) {  // (stored W: the pose is only needed for the trial cost, and is fetched there: 14 registers less across the middle)
 #pragma unroll
     for (int i = 0; i < 7; ++i) ps[i] = poses[7 * cam + i];
   }
@@ -2872,8 +2869,8 @@ __global__ __launch_bounds__(256, MF ? 4 : 5) void k_backsub_flat(DeviceProblem 
   if (mf) {  // the current points to the observation lanes (the same rows take the trial points later, after a barrier)
     if (lm_lane) { myP[3 * lane] = P[0]; myP[3 * lane + 1] = P[1]; myP[3 * lane + 2] = P[2]; }
     __syncthreads();
-    if (act) {
-      const int li = lm - jb;
+    {
+      const int li = have ? lm - jb : 0;
       const double Pc[3] = {myP[3 * li], myP[3 * li + 1], myP[3 * li + 2]};
       double r[2], Jc[12], Jp[6], zc;
       linearize_obs(d.K, ps, Pc, u, v, r, Jc, Jp, zc);
@@ -2941,13 +2938,13 @@ __global__ __launch_bounds__(256, MF ? 4 : 5) void k_backsub_flat(DeviceProblem 
   double cost = 0.0;
   int nbehind = 0, nzero = 0;
   if (with_cost) {
-    if (!mf && act) {
+    if (!mf) {
 #pragma unroll
       for (int i = 0; i < 7; ++i) ps[i] = poses[7 * cam + i];
     }
     __syncthreads();
-    if (act) {
-      const int li = lm - jb;
+    {
+      const int li = have ? lm - jb : 0;
       const double Pt[3] = {myP[3 * li], myP[3 * li + 1], myP[3 * li + 2]};
       double po[7];
       if (f >= 0) retract_pose(ps, dl, po);
@@ -2959,9 +2956,10 @@ __global__ __launch_bounds__(256, MF ? 4 : 5) void k_backsub_flat(DeviceProblem 
       quat_to_R(po + 3, R);
       to_camera(R, po, Pt, X);
       reproject(d.K, X, u, v, r0, r1);
-      nbehind = X[2] <= 0.0;
-      nzero = X[2] == 0.0;
-      cost = !ROBUST ? 0.5 * (r0 * r0 + r1 * r1) : robust_cost(d.loss, r0) + robust_cost(d.loss, r1);
+      nbehind = act && X[2] <= 0.0;
+      nzero = act && X[2] == 0.0;
+      const double cost_k = !ROBUST ? 0.5 * (r0 * r0 + r1 * r1) : robust_cost(d.loss, r0) + robust_cost(d.loss, r1);
+      cost = act ? cost_k : 0.0;
     }
     if (per_comp && have) {
       const int co = act ? sComp[wave][lm - jb] : 0;
