@@ -2381,6 +2381,14 @@ __device__ __forceinline__ double small_block_products(const double B[36], int i
 // iteration, [nc][nc] + a validity flag; null: block-Jacobi alone).  The restriction P^T r is wave-local (an aggregate
 // is 5 or 10 of the 10 cameras of a wave), the nc x nc product is spread over 8 nc threads with the matrix in
 // registers, the prolongation is a read of the aggregate's 6-vector: two more barriers per iteration.
+// -DSMALL_CLOCKS: wall_clock64 cuts (10 ns ticks) inside k_solve_small, printed by thread 0 (a debug build, never the
+// library that ships): set-up, then for the first PCG iterations the block products up to the barrier, the scalars
+// and the gather of w, the vector updates and the preconditioner up to the second barrier
+#ifdef SMALL_CLOCKS
+#define SMALL_CUT(i) do { if (threadIdx.x == 0 && (i) < 32) small_cut[i] = wall_clock64(); } while (0)
+#else
+#define SMALL_CUT(i) do {} while (0)
+#endif
 template <int NB, bool COARSE>
 __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, double lam, double min_diag,
                                                                double tol2, int max_iter, const double* __restrict__ cinv) {
@@ -2497,8 +2505,14 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
         zv[zoff[v]] = zi;
       }
   };
+#ifdef SMALL_CLOCKS
+  long long small_cut[32];
+  for (int i = 0; i < 32; ++i) small_cut[i] = 0;
+  SMALL_CUT(0);
+#endif
   precondition();
   __syncthreads();
+  SMALL_CUT(1);
   double gamma = 0.0, gamma0 = 0.0, delta_ = 0.0, inv_gamma_old = 1.0, denom_old = 1.0;
   static_assert(SMALL_THREADS == 512, "the partial sums below are written out for 8 waves");
   int it = 0;
@@ -2517,7 +2531,9 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
     pg = wave_sum_dpp(pg);
     pd = wave_sum_dpp(pd);
     if (lane == 0) { red[2 * wv] = pg; red[2 * wv + 1] = pd; }
+    SMALL_CUT(2 + 4 * it);
     __syncthreads();
+    SMALL_CUT(3 + 4 * it);
     {
       const double g01 = red[0] + red[2], g23 = red[4] + red[6], g45 = red[8] + red[10], g67 = red[12] + red[14];
       const double d01 = red[1] + red[3], d23 = red[5] + red[7], d45 = red[9] + red[11], d67 = red[13] + red[15];
@@ -2560,11 +2576,22 @@ __global__ __launch_bounds__(SMALL_THREADS) void k_solve_small(DeviceProblem d, 
         r[v] -= alpha * sv[v];
         rv[zoff[v]] = r[v];
       }
+    SMALL_CUT(4 + 4 * it);
     __builtin_amdgcn_wave_barrier();  // the 6 rows of a camera belong to this wave: LDS keeps a wave's accesses in order
     precondition();
+    SMALL_CUT(5 + 4 * it);
     ++it;
     __syncthreads();
   }
+#ifdef SMALL_CLOCKS
+  if (threadIdx.x == 0) {
+    printf("k_solve_small its %d: setup->loop %lld |", it, small_cut[1] - small_cut[0]);
+    for (int q = 0; q < 6; ++q)
+      printf(" [prod %lld bar %lld scal+gather+upd %lld precond %lld next %lld]", small_cut[2 + 4 * q] - (q ? small_cut[1 + 4 * q] : small_cut[1]),
+             small_cut[3 + 4 * q] - small_cut[2 + 4 * q], small_cut[4 + 4 * q] - small_cut[3 + 4 * q], small_cut[5 + 4 * q] - small_cut[4 + 4 * q], small_cut[6 + 4 * q] - small_cut[5 + 4 * q]);
+    printf(" (x10 ns)\n");
+  }
+#endif
 #pragma unroll
   for (int v = 0; v < SMALL_VPT; ++v)
     if (ent[v] >= 0) d.dc[ent[v]] = x[v];
