@@ -81,16 +81,21 @@ def test_jacobian_blocks_vs_finite_differences(golden, name):
             assert np.abs(Jp[sel][:, :, k] - fd[sel]).max() <= 1e-6 * np.abs(fd[sel]).max()
 
 
-@pytest.mark.parametrize("lin", ["default", "window", "group", "matrix_free"])
+@pytest.mark.parametrize("lin", ["default", "flat", "window", "group", "matrix_free"])
 @pytest.mark.parametrize("name", ["test_scene_convergence", "noisy_10x300"])
 def test_normal_equation_blocks_match_oracle(golden, name, lin, monkeypatch):
     """U, V, W, gradients, Schur complement S, reduced rhs and the LM step against the numpy
-    restatement; fp64 sums in different orders: 1e-10 relative to the largest entry.  With each of the three
-    linearisation kernels: the default for few cameras (k_linearize_flat), k_linearize_win (what problems with more
-    than 64 cameras take) and the group-per-track k_linearize<G> (tracks longer than 32); and on the matrix-free path."""
-    if lin == "window":
+    restatement; fp64 sums in different orders: 1e-10 relative to the largest entry.  With each of the
+    linearisation kernels: the default (k_linearize_rows, round 3: fixed-order sums), round 2's kernels that stay in
+    the tree behind BA_LIN_ROWS=0 (k_linearize_flat for few cameras, k_linearize_win for more than 64) and the
+    group-per-track k_linearize<G> (tracks longer than 32); and on the matrix-free path."""
+    if lin == "flat":
+        monkeypatch.setenv("BA_LIN_ROWS", "0")
+    elif lin == "window":
+        monkeypatch.setenv("BA_LIN_ROWS", "0")
         monkeypatch.setenv("BA_LIN_WIN", "1")
     elif lin == "group":
+        monkeypatch.setenv("BA_LIN_ROWS", "0")
         monkeypatch.setenv("BA_LIN_WIN", "0")
         monkeypatch.setenv("BA_LIN_FLAT", "0")
     elif lin == "matrix_free":  # no stored W: the Schur and back-substitution kernels rebuild it (the default from 2 M observations)
@@ -100,6 +105,13 @@ def test_normal_equation_blocks_match_oracle(golden, name, lin, monkeypatch):
     C, L = n_poses + 1, len(pts)
     lam = 1e-3
     with _solver(g, pcg_tol=1e-13, pcg_max_iter=2000) as s:
+        flags = s.problem_info()["linearize_flat"]  # bits: 1 k_linearize_flat possible, 8 k_linearize_win, 16 k_linearize_rows
+        assert bool(flags & 16) == (lin in ("default", "matrix_free")), flags
+        assert bool(flags & 8) == (lin == "window"), flags
+        if lin == "flat":
+            assert flags & 1 and not flags & 8, flags
+        if lin == "group":
+            assert not flags & (1 | 8 | 16), flags
         out = s.debug_linearization(poses, pts, lam)
     r, Jc, Jp = lm.linearize(poses, pts, g["obs_cam"], g["obs_pt"], g["obs_uv"], g["intr"])
     free = np.ones(C, bool)
@@ -121,22 +133,28 @@ def test_normal_equation_blocks_match_oracle(golden, name, lin, monkeypatch):
 
 
 def test_windowed_linearisation_on_an_unstructured_scene():
-    """k_linearize_win where its LDS window overflows: 200 cameras with random visibility, so the four chunks of a
-    workgroup touch far more than 32 cameras and most camera groups go straight to the global slab.  U, g_c, V, g_p, W
-    against the numpy restatement (1e-10 of the largest entry), and the windowed kernel against the group-per-track one."""
+    """k_linearize_win (round 2's kernel, behind BA_LIN_ROWS=0) where its LDS window overflows: 200 cameras with random
+    visibility, so the four chunks of a workgroup touch far more than 32 cameras and most camera groups go straight to
+    the global slab.  U, g_c, V, g_p, W against the numpy restatement (1e-10 of the largest entry), and the windowed
+    kernel against the group-per-track one and against today's k_linearize_rows."""
     import os
     sc = scenes.ring_scene(200, 4000, 5, visibility="random")
     C, L = 200, 4000
     a = (sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
     outs = {}
-    for mode in ("1", "0"):
-        os.environ["BA_LIN_WIN"] = mode
+    for mode in ("1", "0", "rows"):
+        if mode != "rows":
+            os.environ["BA_LIN_ROWS"] = "0"
+            os.environ["BA_LIN_WIN"] = mode
         try:
             with _native.Solver(linear_solver=2) as s:
                 s.set_problem(C, L, *a)
+                flags = s.problem_info()["linearize_flat"]  # bits: 8 k_linearize_win, 16 k_linearize_rows
+                assert bool(flags & 16) == (mode == "rows") and bool(flags & 8) == (mode == "1"), (mode, flags)
                 outs[mode] = s.debug_linearization(sc["poses_guess"], sc["points_guess"], 1e-3, want_S=False)
         finally:
-            del os.environ["BA_LIN_WIN"]
+            os.environ.pop("BA_LIN_ROWS", None)
+            os.environ.pop("BA_LIN_WIN", None)
     r, Jc, Jp = lm.linearize(sc["poses_guess"], sc["points_guess"], *a)
     free = np.ones(C, bool)
     free[0] = False
@@ -145,7 +163,8 @@ def test_windowed_linearisation_on_an_unstructured_scene():
     for mode, out in outs.items():
         for k, ref in (("U", U), ("V", V), ("W", W), ("gc", gc), ("gp", gp)):
             np.testing.assert_allclose(out[k], ref, rtol=0, atol=1e-10 * np.abs(ref).max(), err_msg=f"{k} (BA_LIN_WIN={mode})")
-    np.testing.assert_allclose(outs["1"]["dc"], outs["0"]["dc"], rtol=0, atol=1e-9 * np.abs(outs["0"]["dc"]).max())
+    for mode in ("1", "rows"):
+        np.testing.assert_allclose(outs[mode]["dc"], outs["0"]["dc"], rtol=0, atol=1e-9 * np.abs(outs["0"]["dc"]).max())
 
 
 @pytest.mark.parametrize("name", ["noisy_10x300", "ring_50x2000"])
