@@ -314,6 +314,7 @@ def test_large_system_path_matches_small_path():
         try:
             with _native.Solver(pcg_tol=1e-6, linear_solver=1) as s:
                 s.set_problem(C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+                assert (s.problem_info()["reduced_solver"] == 1) == (small == "1")  # 1: k_solve_small, 0: the multi-kernel PCG
                 out.append(s.solve(sc["poses_guess"], sc["points_guess"]))
         finally:
             os.environ.pop("BA_SMALL_SOLVE", None)
@@ -394,6 +395,7 @@ def test_unstructured_visibility_matches_oracle():
         try:
             with _native.Solver() as s:
                 s.set_problem(C, L, sc["obs_cam"], sc["obs_pt"], sc["obs_uv"], sc["intr"])
+                assert (s.problem_info()["contrib_rows"] > 0) == (staged == "1")  # the staged kernel's tiles exist or not
                 out = s.debug_linearization(sc["poses_guess"], sc["points_guess"], 1e-3, want_S=True)
                 _, _, rep = s.solve(sc["poses_guess"], sc["points_guess"])
         finally:
