@@ -1930,16 +1930,19 @@ __global__ __launch_bounds__(64, 2) void k_schur_staged(DeviceProblem d, double 
   if (nbad) atomic_add_f64(&SCAL_MINE(d)[SC_BADV], (double)nbad);
 }
 
+// (eight waves per S block since late round 3: the launch lasts as long as its heaviest block, a diagonal one, whose rows
+// are twice the average; with four waves config 2 took 13.4 us)
+constexpr int GATHER_WAVES = 8, GATHER_THREADS = 64 * GATHER_WAVES;
 // k_gather_S (staged path): S (upper blocks) = sum of the contribution rows that the inverted index
 // lists for each block (+ partial U on the diagonal blocks), rhs = partial gc + the rows' rhs part,
 // Ugc = partial U/gc (the diagonal blocks also sum their camera's k_linearize slabs: no k_reduce_U
-// launch on this path).  One 256-thread block per S block: wave w takes rows w, w + 4, ... of the
-// list (lanes 0..41 = the 42 entries of a row, 8 rows in flight per wave), the four partial sums are
+// launch on this path).  One 512-thread block per S block: wave w takes rows w, w + 8, ... of the
+// list (lanes 0..41 = the 42 entries of a row, 16 rows in flight per wave), the eight partial sums are
 // combined in a fixed order.  Reads every contribution row once: 336 B per (pair, run, block of
 // k_schur_staged).
-__global__ __launch_bounds__(256) void k_gather_S(DeviceProblem d, int solver_mode, double lam, double min_diag,
+__global__ __launch_bounds__(GATHER_THREADS) void k_gather_S(DeviceProblem d, int solver_mode, double lam, double min_diag,
                                                   int precond, double* __restrict__ csum) {
-  __shared__ double part[4][64];
+  __shared__ double part[GATHER_WAVES][64];
   __shared__ double sblk[36];
   __shared__ double upart[8][32];
   __shared__ double ugc[32];
@@ -1955,7 +1958,7 @@ __global__ __launch_bounds__(256) void k_gather_S(DeviceProblem d, int solver_mo
   const bool diag = extra || d.low_of[s] < 0;
   const int f = d.urow[s];
   const long cam27 = (long)(extra ? d.fixed_cams[blockIdx.x - d.nu] : d.free2cam[f]) * 27;
-  if (diag) {
+  if (diag && threadIdx.x < 256) {  // (eight groups of 32 threads, as when the workgroup had 256)
     // this camera's U (21) | gc (6): sum of the k_linearize slabs (k_reduce_U's job, fused here), or
     // the values kept from the last linearisation when this is a re-solve with another damping
     const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
@@ -1985,11 +1988,11 @@ __global__ __launch_bounds__(256) void k_gather_S(DeviceProblem d, int solver_mo
   double acc[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) acc[u] = 0.0;
-  // wave w takes rows r0 + w + 4 k.  Lane l first fetches the row number of k = kb + l (one load for 64
+  // wave w takes rows r0 + w + GATHER_WAVES k.  Lane l first fetches the row number of k = kb + l (one load for 64
   // rows), then the rows are read 16 at a time: no contribution load waits for an index load.
-  const int cnt = (r1 - r0 - w + 3) >> 2;  // rows of this wave
+  const int cnt = (r1 - r0 - w + GATHER_WAVES - 1) / GATHER_WAVES;  // rows of this wave
   for (int kb = 0; kb < cnt; kb += 64) {
-    const int mine = (kb + lane < cnt) ? d.ctr_row[r0 + w + 4 * (kb + lane)] : 0;
+    const int mine = (kb + lane < cnt) ? d.ctr_row[r0 + w + GATHER_WAVES * (kb + lane)] : 0;
     const int m = min(64, cnt - kb);
     for (int k0 = 0; k0 < m; k0 += 16) {
       double v[16];
@@ -2014,7 +2017,9 @@ __global__ __launch_bounds__(256) void k_gather_S(DeviceProblem d, int solver_mo
   }
   __syncthreads();
   if (extra || w != 0 || lane >= (diag ? CTR_ROW : 36)) return;
-  double sum = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  static_assert(GATHER_WAVES == 8, "the fold below is written out for eight waves");
+  double sum = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) +
+               ((part[4][lane] + part[5][lane]) + (part[6][lane] + part[7][lane]));
   if (lane < 36) {
     if (diag) {
       const int i = lane / 6, c = lane - 6 * i;

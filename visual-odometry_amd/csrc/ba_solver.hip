@@ -654,7 +654,7 @@ int do_reduced_solve(ba_handle* h, double lam, int* pcg_iters) {
   if (h->schur_cpb > 0 && h->gather_wave && !fused_precond)
     launch_timed(h, KT_GATHER, k_gather_S_wave, grid_for(d.nu + (d.C - d.Cf), 4), 256, d, mode, bsc);
   else if (h->schur_cpb > 0)
-    launch_timed(h, KT_GATHER, k_gather_S, d.nu + (d.C - d.Cf), 256, d, mode, lam, o.min_diag, fused_precond, csum_arg);
+    launch_timed(h, KT_GATHER, k_gather_S, d.nu + (d.C - d.Cf), GATHER_THREADS, d, mode, lam, o.min_diag, fused_precond, csum_arg);
   else launch_timed(h, KT_GATHER, k_reduce_S, grid_for(d.s_slab_stride + 27L * d.C), 256, d, mode);
   const size_t red_count = (size_t)d.nu * 36 + (size_t)6 * d.Cf + (size_t)27 * d.C;
   if (h->world > 1 && h->sharded)  // sharded reduced solve: only rhs | U, gc are summed everywhere; S travels by segment below
