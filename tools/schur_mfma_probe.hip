@@ -217,6 +217,90 @@ __global__ __launch_bounds__(64, 2) void k_valu_pf(const double* __restrict__ W,
   }
 }
 
+// ---------------------------------------------------------------- valu, half a block per lane: two lanes per camera pair (rows 0-2 and 3-5
+// of its 6 x 6 block), two landmarks per step: 18 + 3 accumulators per lane instead of 36 + 6
+template <int MINW>
+__global__ __launch_bounds__(64, MINW) void k_valu_half(const double* __restrict__ W, const double* __restrict__ Lg, long n, int nl,
+                                                        double* __restrict__ out) {
+  __shared__ __align__(16) double sZ[64 * SZ_STRIDE];
+  __shared__ double sL[LPC * 9];
+  const int lane = threadIdx.x, run = blockIdx.x;
+  const int gl = lane & 31, grp = lane >> 5, pr = gl >> 1, hf = gl & 1;
+  int b0 = 0;
+  while ((b0 + 1) * (b0 + 2) / 2 <= pr) ++b0;
+  const int a0 = pr - b0 * (b0 + 1) / 2;
+  double acc[18], accr[3];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) acc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) accr[i] = 0.0;
+  double pw[12], pl[9];
+  auto issue = [&](int c) {
+    const long k0 = ((long)run * nl + (long)c * LPC) * D;
+    const int nc = min(LPC, nl - c * LPC);
+    if (lane < nc * D)
+#pragma unroll
+      for (int r = 0; r < 12; ++r) pw[r] = W[(long)r * n + k0 + lane];
+    if (lane < nc)
+#pragma unroll
+      for (int r = 0; r < 9; ++r) pl[r] = Lg[((long)run * nl + (long)c * LPC + lane) * 9 + r];
+  };
+  const int n_chunks = (nl + LPC - 1) / LPC;
+  issue(0);
+  for (int c = 0; c < n_chunks; ++c) {
+    const int nc = min(LPC, nl - c * LPC);
+    __syncthreads();
+    if (lane < nc)
+#pragma unroll
+      for (int r = 0; r < 9; ++r) sL[lane * 9 + r] = pl[r];
+    __syncthreads();
+    if (lane < nc * D) {
+      double z[18];
+      form_z(pw, &sL[(lane / D) * 9], z);
+#pragma unroll
+      for (int i = 0; i < 18; ++i) sZ[lane * SZ_STRIDE + i] = z[i];
+    }
+    __syncthreads();
+    if (c + 1 < n_chunks) issue(c + 1);
+    for (int l0 = 0; l0 < nc; l0 += 2) {
+      const int li = l0 + grp;
+      if (li < nc && pr < 15) {
+        const int kb = li * D;
+        const double* __restrict__ Ya = &sZ[(kb + a0) * SZ_STRIDE + 9 * hf];
+        const double* __restrict__ Wb = &sZ[(kb + b0) * SZ_STRIDE];
+        double Y[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Y[i] = Ya[i];
+        if (a0 == b0) {
+          const double g0 = sL[li * 9 + 6], g1 = sL[li * 9 + 7], g2 = sL[li * 9 + 8];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) accr[i] = fma(Y[3 * i + 2], g2, fma(Y[3 * i + 1], g1, fma(Y[3 * i], g0, accr[i])));
+        }
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) {
+          const double w0 = Wb[3 * cc], w1 = Wb[3 * cc + 1], w2 = Wb[3 * cc + 2];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) acc[6 * i + cc] = fma(Y[3 * i + 2], w2, fma(Y[3 * i + 1], w1, fma(Y[3 * i], w0, acc[6 * i + cc])));
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 18; ++i) acc[i] += __shfl_xor(acc[i], 32);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) accr[i] += __shfl_xor(accr[i], 32);
+  if (lane < 30) {
+    double* o = out + (long)run * 960;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc) o[(6 * a0 + 3 * hf + i) * 32 + 6 * b0 + cc] = acc[6 * i + cc];
+    if (a0 == b0)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) o[(6 * a0 + 3 * hf + i) * 32 + 30] = accr[i];
+  }
+}
+
 // ---------------------------------------------------------------- mfma: one wave per run, WAVES waves per block
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_mfma(const double* __restrict__ W, const double* __restrict__ Lg, long n, int nl,
@@ -328,6 +412,20 @@ int main(int argc, char** argv) {
     double worst = 0.0;
     for (size_t i = 0; i < h1.size(); ++i) worst = std::fmax(worst, std::fabs(h1[i] - h2[i]));
     std::printf("  (prefetched against plain: largest difference %.3e)\n", worst);
+  }
+  for (int v = 0; v < 3; ++v) {
+    CHECK(hipMemset(o2, 0, (size_t)runs * 960 * 8));
+    if (v == 0) time_it("valu, half blocks, 2 w", [&] { k_valu_half<2><<<runs, 64>>>(dW, dL, n, nl, o2); });
+    if (v == 1) time_it("valu, half blocks, 3 w", [&] { k_valu_half<3><<<runs, 64>>>(dW, dL, n, nl, o2); });
+    if (v == 2) time_it("valu, half blocks, 4 w", [&] { k_valu_half<4><<<runs, 64>>>(dW, dL, n, nl, o2); });
+    std::vector<double> h1((size_t)runs * 960), h2((size_t)runs * 960);
+    CHECK(hipMemcpy(h1.data(), o1, h1.size() * 8, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(h2.data(), o2, h2.size() * 8, hipMemcpyDeviceToHost));
+    double worst = 0.0;
+    for (int r = 0; r < runs; ++r)
+      for (int i = 0; i < 30; ++i)
+        for (int j = i; j < 31; ++j) worst = std::fmax(worst, std::fabs(h1[(size_t)r * 960 + i * 32 + j] - h2[(size_t)r * 960 + i * 32 + j]));
+    std::printf("  (half blocks against plain: largest difference %.3e)\n", worst);
   }
   time_it("mfma, 1 wave / block", [&] { k_mfma<1><<<runs, 64>>>(dW, dL, n, nl, runs, o2); });
   time_it("mfma, 2 waves / block", [&] { k_mfma<2><<<(runs + 1) / 2, 128>>>(dW, dL, n, nl, runs, o2); });
